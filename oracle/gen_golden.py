@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run ONCE in the build
+container, where /root/reference exists; the GPU box never runs this).
+
+TEST INFRASTRUCTURE.  Two kinds of vectors are written:
+
+1. *Reference pins* -- outputs of the reference's own importable Python
+   helpers, executed on CPU through a shim (absent third-party modules are
+   stubbed, ``device="cuda"`` is rewritten to ``"cpu"``):
+     lib/utils/general_utils.py : build_rotation, quaternion_raw_multiply
+     lib/utils/sh_utils.py      : eval_sh, RGB2SH
+     lib/utils/primitive_utils.py: build2DRectangle
+     lib/scene/lidar_sensor.py  : LiDARSensor.get_range_rays (KITTI + Waymo mode)
+   -> tests/golden/conventions.npz, rays_*.npz
+2. *Oracle regression vectors* -- outputs of our CPU restatement
+   (oracle/lrt_oracle.c, float32) on the seeded S10k scene
+   -> tests/golden/s10k_golden.npz, s1m_stats.json.
+   These are NOT outputs of the reference CUDA/OptiX kernels (which cannot
+   run here): parity with the kernels themselves stays "unpinned".
+
+Only data (inputs + expected outputs) is stored; no reference source text.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def _import_reference():
+    import torch
+    from torch.overrides import TorchFunctionMode
+
+    class _Anything(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return _Anything(self.__name__ + "." + name)
+
+        def __call__(self, *a, **k):
+            return _Anything(self.__name__ + "()")
+
+    for name in ["simple_knn", "simple_knn._C", "plyfile", "open3d", "icosphere", "cv2",
+                 "tensorboardX", "lpips", "tqdm", "imageio", "matplotlib", "matplotlib.pyplot",
+                 "matplotlib.cm", "trimesh", "skimage", "skimage.metrics", "roma", "kornia",
+                 "PIL", "PIL.Image", "termcolor", "ruamel", "ruamel.yaml"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = _Anything(name)
+    # the reference's console_utils pip-installs packages at import: stub it
+    cu = _Anything("lib.utils.console_utils")
+    sys.modules["lib.utils.console_utils"] = cu
+
+    class CudaToCpu(TorchFunctionMode):
+        def __torch_function__(self, func, types_, args=(), kwargs=None):
+            kwargs = dict(kwargs or {})
+            dev = kwargs.get("device", None)
+            if dev is not None and "cuda" in str(dev):
+                kwargs["device"] = "cpu"
+            name = getattr(func, "__name__", "")
+            if name == "cuda":
+                return args[0]
+            return func(*args, **kwargs)
+
+    sys.path.insert(0, REF)
+    mode = CudaToCpu()
+    mode.__enter__()
+    from lib.utils import general_utils, sh_utils  # noqa
+    from lib.utils import primitive_utils  # noqa
+    from lib.scene import lidar_sensor  # noqa
+    return torch, general_utils, sh_utils, primitive_utils, lidar_sensor, mode
+
+
+def gen_reference_pins():
+    torch, gu, shu, pu, ls, mode = _import_reference()
+    rng = np.random.default_rng(123)
+    N = 128
+    q = rng.normal(size=(N, 4)).astype(np.float32)          # un-normalised on purpose
+    qt = torch.from_numpy(q)
+    R = gu.build_rotation(qt).numpy()
+    qa = rng.normal(size=(N, 4)).astype(np.float32)
+    qprod = gu.quaternion_raw_multiply(None, torch.from_numpy(qa), qt).numpy()
+
+    means = rng.normal(size=(N, 3)).astype(np.float32) * 10
+    scales = np.exp(rng.uniform(np.log(0.03), np.log(0.25), (N, 2))).astype(np.float32)
+    qn = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    opac = np.clip(1 / (1 + np.exp(-rng.normal(0, 2, (N, 1)))), 0.01, 0.99).astype(np.float32)
+    verts, faces, _ = pu.build2DRectangle(torch.from_numpy(means), torch.from_numpy(scales),
+                                          torch.from_numpy(qn), torch.from_numpy(opac))
+    verts = verts.numpy(); faces = faces.numpy()
+
+    dirs = rng.normal(size=(N, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dirs = dirs.astype(np.float64)
+    sh = rng.normal(size=(N, 3, 16)).astype(np.float64)      # eval_sh layout (..., C, 16)
+    sh_out = {}
+    for deg in range(4):
+        sh_out[f"eval_sh_deg{deg}"] = shu.eval_sh(deg, torch.from_numpy(sh), torch.from_numpy(dirs)).numpy()
+    rgb = rng.uniform(0, 1, (N, 3))
+    rgb2sh = shu.RGB2SH(torch.from_numpy(rgb)).numpy()
+
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "conventions.npz"),
+                        quats=q, build_rotation=R, quat_a=qa, quat_raw_multiply=qprod,
+                        means=means, scales=scales, quats_unit=qn, opacities=opac,
+                        rect_vertices=verts, rect_faces=faces,
+                        sh_dirs=dirs, sh_coeffs_c16=sh, rgb=rgb, rgb2sh=rgb2sh, **sh_out)
+
+    # ---- ray grids from LiDARSensor.get_range_rays
+    def rays(H, W, data_type, bounds, s2w=None, s2e=None):
+        s2e = np.eye(4, dtype=np.float32) if s2e is None else s2e
+        sensor = ls.LiDARSensor(s2e, "top", bounds, data_type)
+        sensor.H, sensor.W = H, W
+        s2w = torch.eye(4) if s2w is None else torch.from_numpy(s2w)
+        sensor.sensor2world[0] = s2w.float()
+        sensor.sensor_center[0] = s2w[:3, 3].float()
+        o, d = sensor.get_range_rays(0)
+        assert not o.is_contiguous() or H * W == 1       # expanded view in the reference
+        return o.contiguous().numpy(), d.contiguous().numpy()
+
+    import math
+    kb = [math.radians(-24.9), math.radians(2.0)]          # kitti_loader/__init__.py:187
+    o, d = rays(16, 256, "KITTI", kb)
+    np.savez_compressed(os.path.join(OUT, "rays_kitti_16x256.npz"), ray_o=o, ray_d=d,
+                        inc_bounds_deg=np.array([-24.9, 2.0]))
+    o, d = rays(64, 2048, "KITTI", kb)
+    np.savez_compressed(os.path.join(OUT, "rays_kitti_64x2048_sample.npz"),
+                        rows=np.arange(0, 64, 7), cols=np.arange(0, 2048, 61),
+                        ray_d=d[::7, ::61], sha256=hashlib.sha256(d.tobytes()).hexdigest(),
+                        inc_bounds_deg=np.array([-24.9, 2.0]))
+    # a posed KITTI sensor and a Waymo-mode grid (per-beam inclination table + yaw offset)
+    ang = 0.3
+    s2w = np.eye(4, dtype=np.float32)
+    s2w[:3, :3] = np.array([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1]], np.float32)
+    s2w[:3, 3] = [1.5, -2.0, 1.8]
+    o, d = rays(8, 32, "KITTI", kb, s2w=s2w)
+    np.savez_compressed(os.path.join(OUT, "rays_kitti_posed_8x32.npz"), ray_o=o, ray_d=d, sensor2world=s2w)
+    beams = np.linspace(-0.31, 0.04, 8).astype(np.float32).tolist()
+    o, d = rays(8, 40, "Waymo", beams, s2w=s2w, s2e=s2w)
+    np.savez_compressed(os.path.join(OUT, "rays_waymo_8x40.npz"), ray_o=o, ray_d=d, sensor2world=s2w,
+                        beam_inclinations=np.array(beams, np.float32))
+    mode.__exit__(None, None, None)
+    print("reference pins written to", OUT)
+
+
+def gen_oracle_vectors(with_s1m: bool):
+    from lidar_rt_amd import scenes
+    from oracle import oracle
+    sc, o, d = scenes.s10k()
+    orc = oracle.Oracle(sc["means"], sc["scales"], sc["rotations"], sc["opacities"], "f32")
+    fw = orc.forward(o, d, sc["shs"], 3, scenes.BG_DEFAULT, stats=True)
+    dL = scenes.upstream_grad(16, 256)
+    bw = orc.backward(o, d, sc["shs"], 3, scenes.BG_DEFAULT, fw["out"], dL)
+    np.savez_compressed(os.path.join(OUT, "s10k_golden.npz"),
+                        out=fw["out"], accum=fw["accum"], n_cand=fw["n_cand"], n_comp=fw["n_comp"],
+                        d_means=bw["means"], d_shs=bw["shs"], d_opacities=bw["opacities"],
+                        d_scales=bw["scales"], d_rotations=bw["rotations"],
+                        scene_sha256=hashlib.sha256(b"".join(sc[k].tobytes() for k in sorted(sc))).hexdigest())
+    print("s10k: C=%.3f K=%.3f" % (fw["n_cand"].mean(), fw["n_comp"].mean()))
+    if with_s1m:
+        sc, o, d = scenes.s1m()
+        orc = oracle.Oracle(sc["means"], sc["scales"], sc["rotations"], sc["opacities"], "f32")
+        fw = orc.forward(o, d, sc["shs"], 3, scenes.BG_DEFAULT, stats=True)
+        nc, nk = fw["n_cand"], fw["n_comp"]
+        C, K = float(nc.mean()), float(nk.mean())
+        stats = {
+            "scene": "S1M", "P": 1_000_000, "H": 64, "W": 2048, "sh_degree": 3, "seed": scenes.SEED,
+            "C_mean_candidates_per_ray": C, "K_mean_composited_per_ray": K,
+            "K_median": float(np.median(nk)), "K_p95": float(np.percentile(nk, 95)), "K_max": int(nk.max()),
+            "C_max": int(nc.max()),
+            "B_ray_bytes_fwd_bwd_deg3": 156 + 80 * C + 856 * K,
+            "B_ray_bytes_fwd_deg3": 60 + 40 * C + 200 * K,
+            "B_ray_bytes_bwd_deg3": 96 + 40 * C + 656 * K,
+            "frac_saturated_T_lt_1e-3": float((fw["out"][..., 8] < 1e-3).mean()),
+            "out_channel_means": [float(x) for x in fw["out"].reshape(-1, 9).mean(0)],
+            "out_sha256_f32_oracle": hashlib.sha256(fw["out"].tobytes()).hexdigest(),
+            "K_hist_bins_of_8": np.bincount(np.minimum(nk.ravel() // 8, 31), minlength=32).tolist(),
+            "scene_sha256": hashlib.sha256(b"".join(sc[k].tobytes() for k in sorted(sc))).hexdigest(),
+        }
+        with open(os.path.join(OUT, "s1m_stats.json"), "w") as f:
+            json.dump(stats, f, indent=1)
+        print("s1m: C=%.3f K=%.3f" % (C, K))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--s1m", action="store_true", help="also compute S1M statistics (needs ~1 min)")
+    a = ap.parse_args()
+    if not a.skip_reference:
+        gen_reference_pins()
+    gen_oracle_vectors(a.s1m)
