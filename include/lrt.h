@@ -1,0 +1,96 @@
+/*
+ * lrt.h -- C ABI of the MI355X-native differentiable LiDAR Gaussian tracer
+ * (liblrt_hip.so).  Drop-in boundary for the native half of
+ * zju3dv/LiDAR-RT's `diff_lidar_tracer` operator:
+ *
+ *   lrt_create / lrt_destroy   <-> OptiXStateWrapper ctor/dtor
+ *                                  (DLT/optix_tracer/optix_wrapper.cpp:177-233, DLT/ext.cpp:19)
+ *   lrt_build                  <-> BuildAccelerationStructure (DLT/trace_surfels.cpp:46-148, ext.cpp:20)
+ *                                  + build2DRectangle (lib/utils/primitive_utils.py:182-224): the quads are
+ *                                  derived from the Gaussian parameters on the device, a software LBVH
+ *                                  replaces the OptiX GAS.
+ *   lrt_forward                <-> TraceSurfelsCUDA          (DLT/trace_surfels.cpp:152-265, ext.cpp:21)
+ *   lrt_backward               <-> TraceSurfelsBackwardCUDA  (DLT/trace_surfels.cpp:269-386, ext.cpp:22)
+ *
+ * (DLT = submodules/diff-lidar-tracer in the reference tree.)
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer to contiguous float32 / int32,
+ *    borrowed for the duration of the call's work on `stream`; nothing is
+ *    retained except by lrt_build (which copies what it needs into the state).
+ *  - `stream` is a hipStream_t (NULL = default stream).  All work is
+ *    stream-ordered; no call synchronises the host except when the internal
+ *    workspace has to grow (first call / larger problem).
+ *  - return 0 on success, negative on error; lrt_last_error() gives the text
+ *    (thread-local).  Unlike the reference (common.h:38-50 only prints) every
+ *    HIP failure is reported.
+ *  - layouts: rays (H,W,3) row-major; out (H,W,9) = [C0,C1,C2,D,W,Nx,Ny,Nz,T]
+ *    (config.h:19-24); shs (P,M,3); rotations (w,x,y,z); scales (P,2) post-exp;
+ *    opacities (P) post-sigmoid.
+ */
+#ifndef LRT_H_INCLUDED
+#define LRT_H_INCLUDED
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrt_state lrt_state;
+
+#define LRT_OK 0
+#define LRT_ERR_ARG (-1)
+#define LRT_ERR_HIP (-2)
+#define LRT_ERR_STATE (-3)
+
+/* ABI version of this header (bumped on any signature change). */
+int lrt_abi_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* lrt_last_error(void);
+
+/* Create / destroy a tracer state bound to HIP device `device`. */
+lrt_state* lrt_create(int device);
+void lrt_destroy(lrt_state* st);
+
+/* Build the acceleration structure for P Gaussians (replaces build2DRectangle + the OptiX GAS build).
+ *   means (P,3), scales (P,2), rotations (P,4), opacities (P)
+ *   scale_modifier: TracingSettings.scale_modifier (1.0 in the reference's caller) */
+int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
+              const float* opacities, float scale_modifier, void* stream);
+
+/* Forward trace.  Requires a prior lrt_build with the same P.
+ *   ray_o, ray_d (H,W,3); shs (P,M,3); sh_degree in 0..3, (sh_degree+1)^2 <= M;
+ *   background: device pointer to 3 floats.
+ *   out9 (H,W,9), accum (P): written (accum is zero-filled first).
+ *   out_i32 (H,W) optional (may be NULL): filled with -1 like the reference (trace_surfels.cpp:208).
+ *   training: forwarded flag (unused by the reference kernels). */
+int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M,
+                int sh_degree, const float* shs, const float* background, int training, float* out9,
+                int32_t* out_i32, float* accum, void* stream);
+
+/* Backward trace: re-traces like the reference (backward.cu:513) and scatters the analytic gradients.
+ *   means/scales/rotations/opacities: the same parameter tensors given to lrt_build.
+ *   out9: forward output; dL_dout9 (H,W,9): upstream gradient.
+ *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): zero-filled, then accumulated. */
+int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M,
+                 int sh_degree, const float* means, const float* scales, const float* rotations,
+                 const float* opacities, const float* shs, const float* background, const float* out9,
+                 const float* dL_dout9, float* d_means, float* d_shs, float* d_opacities, float* d_scales,
+                 float* d_rotations, void* stream);
+
+/* Optional instrumentation: when enabled, lrt_forward accumulates
+ * stats[0] = candidate hits consumed, stats[1] = composited hits, stats[2] = traversal passes (ray-tile restarts),
+ * stats[3] = BVH nodes visited (wave level), stats[4] = leaf primitives tested (wave level)
+ * into a device-side counter block; lrt_get_stats copies it to the host (synchronises `stream`). */
+int lrt_enable_stats(lrt_state* st, int enable);
+int lrt_get_stats(lrt_state* st, uint64_t stats_out[8], void* stream);
+
+/* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays). */
+int lrt_set_option(lrt_state* st, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRT_H_INCLUDED */

@@ -1,0 +1,65 @@
+"""ctypes binding of liblrt_hip.so (the C ABI declared in include/lrt.h).
+
+This is the ONLY compute path of the package: there is no CPU fallback.  If
+the shared library is missing or does not load, importing / calling fails
+loudly.  torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "liblrt_hip.so")
+
+EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_forward",
+           "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option")
+
+_lib = None
+
+
+class LrtError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblrt_hip.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must be imported first: brings libamdhip64 into the process)
+    if not os.path.exists(LIB_PATH):
+        raise LrtError(f"{LIB_PATH} is missing: build it with `python -m lidar_rt_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.lrt_abi_version.restype = ci
+    lib.lrt_last_error.restype = C.c_char_p
+    lib.lrt_create.restype = vp; lib.lrt_create.argtypes = [ci]
+    lib.lrt_destroy.restype = None; lib.lrt_destroy.argtypes = [vp]
+    lib.lrt_build.restype = ci
+    lib.lrt_build.argtypes = [vp, ci, vp, vp, vp, vp, cf, vp]
+    lib.lrt_forward.restype = ci
+    lib.lrt_forward.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
+    lib.lrt_backward.restype = ci
+    lib.lrt_backward.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+                                 vp, vp, vp, vp, vp, vp]
+    lib.lrt_enable_stats.restype = ci; lib.lrt_enable_stats.argtypes = [vp, ci]
+    lib.lrt_get_stats.restype = ci; lib.lrt_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+    lib.lrt_set_option.restype = ci; lib.lrt_set_option.argtypes = [vp, C.c_char_p, ci]
+    if lib.lrt_abi_version() != 1:
+        raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise LrtError(f"{what} failed ({rc}): {load().lrt_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr()) if t.numel() > 0 else None

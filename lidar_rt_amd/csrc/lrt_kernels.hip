@@ -1,0 +1,653 @@
+// lrt_kernels.hip -- MI355X (gfx950 / CDNA4) differentiable LiDAR Gaussian tracer.
+//
+// What this file replaces in the reference (zju3dv/LiDAR-RT, DLT = submodules/diff-lidar-tracer):
+//   lib/utils/primitive_utils.py:182-224   build2DRectangle      -> k_make_records (quads are implicit)
+//   DLT/trace_surfels.cpp:46-148           OptiX GAS build        -> software LBVH (Morton sort via rocPRIM
+//                                                                   + implicit 8-wide tree, level-synchronous)
+//   DLT/optix_tracer/forward.cu:146-356    raygen + anyhit (fwd)  -> k_trace<false>
+//   DLT/optix_tracer/backward.cu:434-739   raygen + anyhit (bwd)  -> k_trace<true>
+//   DLT/trace_surfels.cpp:152-386          host launch code       -> lrt_forward / lrt_backward
+//
+// Design: one 64-lane wavefront owns a TILE of 64 neighbouring rays of the range image and walks
+// the BVH as a packet: node and splat data are wave-uniform (scalar loads -> SGPR broadcast, each byte fetched
+// once per tile instead of once per ray), the traversal stack lives in ONE VGPR indexed by lane
+// (v_readlane/v_writelane), `__ballot` decides which children any ray still needs, and every lane keeps the
+// reference's 16-slot nearest-hit buffer in registers.  After each traversal the lanes composite their sorted
+// chunk exactly like the reference's raygen loop and restart behind the 16th hit (+STEP_EPSILON).
+// Wavefronts are persistent: they pull tiles from a device-side counter until the image is done.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/lrt.h"
+#include "lrt_math.h"
+
+#define LRT_LEAF 8            // primitives per leaf (tested exhaustively by the packet)
+#define LRT_NODE_FLOATS 64    // 48 box floats (SoA lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]) + header, 256 B
+#define LRT_MAX_LEVELS 12
+#define LRT_INF __int_as_float(0x7f800000)
+
+static thread_local char g_err[512] = "";
+#define LRT_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    LRT_FAIL(LRT_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+
+struct lrt_state {
+    int device;
+    int P;               // primitives in the current BVH (-1: none)
+    float mod;
+    // grow-only workspace
+    size_t capP;
+    float* rec;          // capP * 16   sorted splat records
+    float* aabb;         // capP * 6    sorted quad AABBs (build only)
+    uint64_t *keys_a, *keys_b;
+    uint32_t *vals_a, *vals_b;
+    void* sort_tmp; size_t sort_tmp_bytes;
+    float* nodes; size_t cap_nodes;
+    unsigned* bounds;    // 6 ordered-uint (min xyz, max xyz)
+    unsigned* tile_counter;
+    unsigned long long* stats;   // 8 counters
+    int stats_enabled;
+    int tile_w_log2;
+    int n_nodes, n_leaves;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ unsigned wave_sum_u(unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+
+// ---------------------------------------------------------------------------------------------------
+// LBVH build
+__global__ void k_bounds(int P, const float* __restrict__ means, const float* __restrict__ opac, unsigned* bounds)
+{
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P; g += gridDim.x * blockDim.x) {
+        float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+        bool ok = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
+        if (ok) {
+            lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+            hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+        }
+    }
+    for (int i = 0; i < 3; i++) { lo[i] = wave_min(lo[i]); hi[i] = wave_max(hi[i]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 3; i++) { atomicMin(bounds + i, f2ord(lo[i])); atomicMax(bounds + 3 + i, f2ord(hi[i])); }
+}
+
+__global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
+                         const unsigned* __restrict__ bounds, uint64_t* keys, uint32_t* vals)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    float lo[3], ext = 0.f;
+    for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
+    float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+    bool ok = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
+    uint64_t key = 0x7fffffffffffffffULL;                       // unhittable primitives sort to the end
+    if (ok) {
+        float s = ext > 0.f ? 2097151.0f / ext : 0.f;           // cubic cells: isotropic locality
+        uint32_t cx = (uint32_t)fminf(fmaxf((x - lo[0]) * s, 0.f), 2097151.f);
+        uint32_t cy = (uint32_t)fminf(fmaxf((y - lo[1]) * s, 0.f), 2097151.f);
+        uint32_t cz = (uint32_t)fminf(fmaxf((z - lo[2]) * s, 0.f), 2097151.f);
+        key = lrt_morton63(cx, cy, cz);
+    }
+    keys[g] = key; vals[g] = (uint32_t)g;
+}
+
+// One thread per sorted slot: quad record + AABB from the raw Gaussian (fused build2DRectangle).
+__global__ void k_make_records(int P, const uint32_t* __restrict__ order, const float* __restrict__ means,
+                               const float* __restrict__ scales, const float* __restrict__ rots,
+                               const float* __restrict__ opac, float mod, float* __restrict__ rec,
+                               float* __restrict__ aabb)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    int g = (int)order[k];
+    float mu[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+    float sc[2] = {scales[2 * g], scales[2 * g + 1]};
+    float q[4] = {rots[4 * g], rots[4 * g + 1], rots[4 * g + 2], rots[4 * g + 3]};
+    float r[LRT_REC_FLOATS]; LrtSplatAux aux;
+    lrt_make_splat(mu, sc, q, opac[g], mod, g, r, &aux);
+    float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
+    dst[0] = make_float4(r[0], r[1], r[2], r[3]);   dst[1] = make_float4(r[4], r[5], r[6], r[7]);
+    dst[2] = make_float4(r[8], r[9], r[10], r[11]); dst[3] = make_float4(r[12], r[13], r[14], r[15]);
+    float* a = aabb + (size_t)k * 6;
+    a[0] = aux.lo[0]; a[1] = aux.lo[1]; a[2] = aux.lo[2]; a[3] = aux.hi[0]; a[4] = aux.hi[1]; a[5] = aux.hi[2];
+}
+
+// Level-1 nodes: child c of node j is leaf 8j+c = sorted primitives [LEAF*(8j+c), +LEAF).
+__global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __restrict__ aabb, float* __restrict__ nodes)
+{
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = tid >> 3, c = tid & 7;
+    if (j >= n_nodes_l1) return;
+    int leaf = j * 8 + c;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int k = leaf * LRT_LEAF; k < leaf * LRT_LEAF + LRT_LEAF && k < P; k++) {
+        const float* a = aabb + (size_t)k * 6;
+        for (int i = 0; i < 3; i++) { lo[i] = fminf(lo[i], a[i]); hi[i] = fmaxf(hi[i], a[3 + i]); }
+    }
+    float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
+    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = lo[i]; nd[24 + i * 8 + c] = hi[i]; }
+    if (c == 0) { nd[48] = __int_as_float(j * 8); nd[49] = __int_as_float(1); }   // children = leaves, base leaf 8j
+}
+
+// Level-l nodes (l >= 2): child c of node j is node 8j+c of level l-1.
+__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* __restrict__ nodes)
+{
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = tid >> 3, c = tid & 7;
+    if (j >= n_nodes) return;
+    int ch = j * 8 + c;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    if (ch < n_child) {
+        const float* cn = nodes + (size_t)(child_off + ch) * LRT_NODE_FLOATS;
+        for (int i = 0; i < 3; i++)
+            for (int e = 0; e < 8; e++) { lo[i] = fminf(lo[i], cn[i * 8 + e]); hi[i] = fmaxf(hi[i], cn[24 + i * 8 + e]); }
+    }
+    float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
+    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = lo[i]; nd[24 + i * 8 + c] = hi[i]; }
+    if (c == 0) { nd[48] = __int_as_float(child_off + j * 8); nd[49] = __int_as_float(0); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Trace
+struct TraceParams {
+    int H, W, P, M, deg, nsh;
+    int tw_log2, tiles_x, n_tiles;
+    const float* ray_o; const float* ray_d;
+    const float* rec; const float* nodes;
+    const float* shs; const float* bg;
+    float* out9; float* accum;                      // forward outputs
+    // backward only
+    const float* means; const float* scales; const float* rots; const float* opac; float mod;
+    const float* out9_in; const float* dL_dout;
+    float* d_means; float* d_shs; float* d_opac; float* d_scales; float* d_rots;
+    unsigned* tile_counter;
+    unsigned long long* stats;
+};
+
+#define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
+
+template <bool BWD>
+__global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const float* __restrict__ g_rec,
+                                                const float* __restrict__ g_nodes)
+{
+    __shared__ float s_t[4][LRT_CHUNK][64];
+    __shared__ int   s_g[4][LRT_CHUNK][64];
+    __shared__ float s_a[4][LRT_CHUNK][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int TWm = (1 << p.tw_log2) - 1;
+    const int TH = 64 >> p.tw_log2;
+    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
+    const int nsh = p.nsh;
+    unsigned st_cand = 0, st_comp = 0, st_pass = 0, st_nodes = 0, st_prims = 0;
+
+    for (;;) {
+        unsigned tile = 0;
+        if (lane == 0) tile = atomicAdd(p.tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= (unsigned)p.n_tiles) break;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int h = ty * TH + (lane >> p.tw_log2), w = (tx << p.tw_log2) + (lane & TWm);
+        const bool valid = (h < p.H) && (w < p.W);
+        const size_t r = valid ? ((size_t)h * p.W + w) : 0;
+        float o[3], d[3], inv[3];
+        for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * r + i]; d[i] = p.ray_d[3 * r + i]; inv[i] = 1.0f / d[i]; }
+        float b[16];
+        lrt_sh_basis(p.deg, d, b);
+
+        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f, Wt = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+        float dL[LRT_NCH], fin[LRT_NCH], dL_dbg = 0.f;
+        if (BWD) {
+            for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * r + i]; fin[i] = p.out9_in[LRT_NCH * r + i]; }
+            dL_dbg = dL[0] * bg0 + dL[1] * bg1 + dL[2] * bg2;
+        }
+        float base = __uint_as_float(__float_as_uint(LRT_T_NEAR) - 1u);   // accept t >= 0.2 (forward.cu:214)
+        bool done = !valid;
+
+        for (int pass = 0; pass < 4096; ++pass) {   // hard bound (65k hits per ray) so a bug can never hang the GPU
+            const bool act = !done;
+            if (!__any(act)) break;
+            st_pass++;
+            // ---- per-lane 16-slot nearest-hit buffer (params.h:83-97), ascending in t
+            float kt[LRT_CHUNK], ka[LRT_CHUNK]; int kg[LRT_CHUNK];
+#pragma unroll
+            for (int i = 0; i < LRT_CHUNK; i++) { kt[i] = 1e16f; kg[i] = 0; ka[i] = 0.f; }
+            unsigned cnt = 0;
+
+            // ---- packet traversal; stack entry = (is_leaf << 31) | index, kept in lane sp of one VGPR
+            int stk = 0; int sp = 0;
+            sp = 1;                                                         // root = node 0 in lane 0 (stk == 0)
+            while (sp > 0) {
+                sp--;
+                const unsigned e = (unsigned)__builtin_amdgcn_readlane(stk, sp);
+                if (e & 0x80000000u) {
+                    // ---------------- leaf: every ray of the tile tests every quad of the leaf
+                    const int k0 = (int)(e & 0x7fffffffu) * LRT_LEAF;
+                    const int k1 = min(k0 + LRT_LEAF, p.P);
+                    for (int k = k0; k < k1; ++k) {
+                        const float* rc = g_rec + (size_t)k * LRT_REC_FLOATS;     // wave-uniform -> scalar loads
+                        float t, ao;
+                        bool hit = lrt_splat_hit(rc, o, d, &t, &ao);
+                        hit = hit && act && (t > base) && (t < kt[LRT_CHUNK - 1]);   // anyhit: forward.cu:323
+                        st_prims++;
+                        if (__any(hit)) {
+                            if (hit) {
+                                cnt++;
+                                float ct = t, ca = ao; int cg = __float_as_int(rc[11]);
+#pragma unroll
+                                for (int i = 0; i < LRT_CHUNK; i++) {                 // sorted insert, forward.cu:336-352
+                                    const bool sw = kt[i] > ct;
+                                    const float tt = kt[i], ta = ka[i]; const int tg = kg[i];
+                                    kt[i] = sw ? ct : tt; ka[i] = sw ? ca : ta; kg[i] = sw ? cg : tg;
+                                    ct = sw ? tt : ct; ca = sw ? ta : ca; cg = sw ? tg : cg;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---------------- inner node: 8 child boxes (SoA), slab test per lane, ballot per child
+                    const float* nd = g_nodes + (size_t)e * LRT_NODE_FLOATS;       // wave-uniform
+                    const unsigned cbase = (unsigned)__float_as_int(nd[48]);
+                    const unsigned cleaf = (unsigned)__float_as_int(nd[49]) << 31;
+                    const float tfar = kt[LRT_CHUNK - 1];
+                    unsigned key[8]; int nh = 0;
+                    st_nodes++;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float t0x = (nd[c] - o[0]) * inv[0], t1x = (nd[24 + c] - o[0]) * inv[0];
+                        const float t0y = (nd[8 + c] - o[1]) * inv[1], t1y = (nd[32 + c] - o[1]) * inv[1];
+                        const float t0z = (nd[16 + c] - o[2]) * inv[2], t1z = (nd[40 + c] - o[2]) * inv[2];
+                        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                        const bool hit = act && (tf >= fmaxf(tn, base)) && (tn <= tfar);
+                        const unsigned long long m = __ballot(hit);
+                        unsigned kk = 0xffffffffu;
+                        if (m) {
+                            const int first = __ffsll((long long)m) - 1;
+                            const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tn, 0.f)), first);
+                            kk = (kb & ~7u) | (unsigned)c;
+                            nh++;
+                        }
+                        key[c] = kk;
+                    }
+                    // sort the (distance | child) keys ascending: 19-comparator network, all wave-uniform
+                    CSWAP(key[0], key[1]); CSWAP(key[2], key[3]); CSWAP(key[4], key[5]); CSWAP(key[6], key[7]);
+                    CSWAP(key[0], key[2]); CSWAP(key[1], key[3]); CSWAP(key[4], key[6]); CSWAP(key[5], key[7]);
+                    CSWAP(key[1], key[2]); CSWAP(key[5], key[6]); CSWAP(key[0], key[4]); CSWAP(key[3], key[7]);
+                    CSWAP(key[1], key[5]); CSWAP(key[2], key[6]);
+                    CSWAP(key[1], key[4]); CSWAP(key[3], key[6]);
+                    CSWAP(key[2], key[4]); CSWAP(key[3], key[5]);
+                    CSWAP(key[3], key[4]);
+#pragma unroll
+                    for (int j = 7; j >= 0; j--) {                                    // farthest first -> nearest pops first
+                        if (j < nh) {
+                            const unsigned ent = cleaf | (cbase + (key[j] & 7u));
+                            stk = (lane == sp) ? (int)ent : stk;                    // v_writelane equivalent (uniform ent, sp)
+                            sp++;
+                        }
+                    }
+                }
+            }
+
+            // ---- stage the sorted chunk through LDS so the consume loop can be a real loop
+#pragma unroll
+            for (int i = 0; i < LRT_CHUNK; i++) { s_t[wv][i][lane] = kt[i]; s_g[wv][i][lane] = kg[i]; s_a[wv][i][lane] = ka[i]; }
+            const int nv = (int)min(cnt, (unsigned)LRT_CHUNK);
+            bool stop = false; float last_t = base;
+            for (int i = 0; i < LRT_CHUNK; ++i) {
+                const bool on = act && !stop && (i < nv);
+                if (!__any(on)) break;
+                if (on) {
+                    const float t = s_t[wv][i][lane]; const int g = s_g[wv][i][lane]; const float ao = s_a[wv][i][lane];
+                    last_t = t;
+                    st_cand++;
+                    const float alpha = fminf(LRT_ALPHA_MAX, ao);                       // forward.cu:247
+                    if (alpha >= LRT_ALPHA_MIN) {
+                        const float testT = T * (1.f - alpha);
+                        if (testT < LRT_T_STOP) {
+                            stop = true;                                                // forward.cu:253-257
+                        } else {
+                            const float wgt = alpha * T;
+                            st_comp++;
+                            // ---- colour from SH (forward.cu:67-111), channel 0 clamped only
+                            const float* sh = p.shs + (size_t)g * p.M * 3;
+                            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                            if (nsh == 16 && p.M == 16) {
+                                float v[48];
+                                const float4* s4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                                for (int j = 0; j < 12; j++) { const float4 q4 = s4[j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
+#pragma unroll
+                                for (int k = 0; k < 16; k++) { c0 += b[k] * v[3 * k]; c1 += b[k] * v[3 * k + 1]; c2 += b[k] * v[3 * k + 2]; }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 16; k++)
+                                    if (k < nsh) { c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2]; }
+                            }
+                            c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+                            const bool cl0 = c0 < 0.f;
+                            c0 = fmaxf(c0, 0.f);
+                            if (!BWD) {
+                                C0 += wgt * c0; C1 += wgt * c1; C2 += wgt * c2;
+                                Dd += wgt * t; Wt += wgt;
+                                unsafeAtomicAdd(p.accum + g, wgt);                      // forward.cu:268
+                            } else {
+                                // ---- backward.cu:538-676 for this hit
+                                const float mu[3] = {p.means[3 * g], p.means[3 * g + 1], p.means[3 * g + 2]};
+                                const float sc[2] = {p.scales[2 * g], p.scales[2 * g + 1]};
+                                const float q[4] = {p.rots[4 * g], p.rots[4 * g + 1], p.rots[4 * g + 2], p.rots[4 * g + 3]};
+                                const float op = p.opac[g];
+                                LrtHitGeom hg;
+                                lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+                                const float n0 = hg.R[2], n1 = hg.R[5], n2 = hg.R[8];
+                                C0 += wgt * c0; C1 += wgt * c1; C2 += wgt * c2;
+                                N0 += wgt * n0; N1 += wgt * n1; N2 += wgt * n2;
+                                Dd += wgt * t;
+                                const float i1a = 1.0f / (1.0f - alpha);
+                                float dLa = dL[0] * (T * c0 - (fin[0] - C0) * i1a) + dL[1] * (T * c1 - (fin[1] - C1) * i1a) +
+                                            dL[2] * (T * c2 - (fin[2] - C2) * i1a);
+                                dLa += dL_dbg * (-fin[8] * i1a);                        // D1 (backward.cu:595-598)
+                                dLa += dL[3] * (T * t - (fin[3] - Dd) * i1a);
+                                dLa += dL[5] * (T * n0 - (fin[5] - N0) * i1a) + dL[6] * (T * n1 - (fin[6] - N1) * i1a) +
+                                       dL[7] * (T * n2 - (fin[7] - N2) * i1a);          // D3
+                                dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
+                                const float dL_dG = op * dLa;
+                                unsafeAtomicAdd(p.d_opac + g, hg.G * dLa);
+                                const float dNgs[3] = {dL[5] * wgt, dL[6] * wgt, dL[7] * wgt};
+                                LrtHitGrad gr;
+                                lrt_hit_backward(&hg, o, d, mu, sc, q, op, dL_dG, dL[3] * wgt, dNgs, &gr);
+                                unsafeAtomicAdd(p.d_scales + 2 * g, gr.d_scale[0]);
+                                unsafeAtomicAdd(p.d_scales + 2 * g + 1, gr.d_scale[1]);
+                                for (int i2 = 0; i2 < 4; i2++) unsafeAtomicAdd(p.d_rots + 4 * g + i2, gr.d_rot[i2]);
+                                for (int i2 = 0; i2 < 3; i2++) unsafeAtomicAdd(p.d_means + 3 * g + i2, gr.d_mean[i2]);
+                                const float r0 = cl0 ? 0.f : dL[0] * wgt, r1 = dL[1] * wgt, r2 = dL[2] * wgt;
+                                float* dsh = p.d_shs + (size_t)g * p.M * 3;
+#pragma unroll
+                                for (int k = 0; k < 16; k++)
+                                    if (k < nsh) {
+                                        unsafeAtomicAdd(dsh + 3 * k, b[k] * r0);
+                                        unsafeAtomicAdd(dsh + 3 * k + 1, b[k] * r1);
+                                        unsafeAtomicAdd(dsh + 3 * k + 2, b[k] * r2);
+                                    }
+                            }
+                            T = testT;
+                        }
+                    }
+                }
+            }
+            if (act) {
+                if (stop || cnt < (unsigned)LRT_CHUNK) done = true;                      // forward.cu:282-285
+                else base = last_t + LRT_STEP_EPS;                                      // forward.cu:288
+            }
+        }
+
+        if (!BWD && valid) {
+            float* op_ = p.out9 + LRT_NCH * r;
+            op_[0] = C0 + T * bg0; op_[1] = C1 + T * bg1; op_[2] = C2 + T * bg2;
+            op_[3] = Dd; op_[4] = Wt; op_[5] = 0.f; op_[6] = 0.f; op_[7] = 0.f; op_[8] = T;
+        }
+    }
+    if (p.stats) {
+        const unsigned a = wave_sum_u(st_cand), c = wave_sum_u(st_comp);
+        if (lane == 0) {
+            atomicAdd(p.stats + 0, (unsigned long long)a); atomicAdd(p.stats + 1, (unsigned long long)c);
+            atomicAdd(p.stats + 2, (unsigned long long)st_pass); atomicAdd(p.stats + 3, (unsigned long long)st_nodes);
+            atomicAdd(p.stats + 4, (unsigned long long)st_prims);
+        }
+    }
+}
+
+__global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) ok = false; else if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false; target = dev; }
+    ~DeviceGuard() { if (prev >= 0 && prev != target) (void)hipSetDevice(prev); }
+    int target;
+};
+
+static int tree_layout(int P, int* n_leaves, int* n_levels, int cnt[LRT_MAX_LEVELS], int off[LRT_MAX_LEVELS])
+{
+    // level 1 .. L ; cnt[l] nodes at level l ; root (level L) stored first: off[L] = 0
+    int nl = (P + LRT_LEAF - 1) / LRT_LEAF;
+    *n_leaves = nl;
+    int L = 0, c = nl;
+    do { c = (c + 7) / 8; if (c < 1) c = 1; L++; cnt[L] = c; } while (c > 1 && L < LRT_MAX_LEVELS - 1);
+    *n_levels = L;
+    int o = 0;
+    for (int l = L; l >= 1; l--) { off[l] = o; o += cnt[l]; }
+    return o;   // total nodes
+}
+
+static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
+{
+    size_t need = (size_t)(P > 0 ? P : 1);
+    if (need <= st->capP) return LRT_OK;
+    HIPCHK(hipStreamSynchronize(stream));
+    size_t cap = need + need / 8 + 1024;
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes};
+    for (void* q : olds) (void)hipFree(q);
+    st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
+    st->capP = 0;
+    HIPCHK(hipMalloc(&st->rec, cap * LRT_REC_FLOATS * sizeof(float)));
+    HIPCHK(hipMalloc(&st->aabb, cap * 6 * sizeof(float)));
+    HIPCHK(hipMalloc(&st->keys_a, cap * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&st->keys_b, cap * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&st->vals_a, cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&st->vals_b, cap * sizeof(uint32_t)));
+    size_t tmp = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, cap, 0, 63, stream));
+    st->sort_tmp_bytes = tmp + 256;
+    HIPCHK(hipMalloc(&st->sort_tmp, st->sort_tmp_bytes));
+    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
+    int total = tree_layout((int)cap, &nl, &L, cnt, off);
+    st->cap_nodes = (size_t)total + 16;
+    HIPCHK(hipMalloc(&st->nodes, st->cap_nodes * LRT_NODE_FLOATS * sizeof(float)));
+    st->capP = cap;
+    return LRT_OK;
+}
+
+extern "C" {
+
+int lrt_abi_version(void) { return 1; }
+const char* lrt_last_error(void) { return g_err; }
+
+lrt_state* lrt_create(int device)
+{
+    g_err[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        snprintf(g_err, sizeof(g_err), "lrt_create: no HIP device %d (count %d)", device, n);
+        return nullptr;
+    }
+    DeviceGuard dg(device);
+    lrt_state* st = new lrt_state();
+    memset(st, 0, sizeof(*st));
+    st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
+    if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
+        hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "lrt_create: hipMalloc failed");
+        delete st;
+        return nullptr;
+    }
+    return st;
+}
+
+void lrt_destroy(lrt_state* st)
+{
+    if (!st) return;
+    DeviceGuard dg(st->device);
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->bounds, st->tile_counter, st->stats};
+    for (void* q : olds) (void)hipFree(q);
+    delete st;
+}
+
+int lrt_set_option(lrt_state* st, const char* name, int value)
+{
+    if (!st || !name) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: null argument");
+    if (!strcmp(name, "tile_w")) {
+        int l2 = -1;
+        for (int i = 0; i <= 6; i++) if ((1 << i) == value) l2 = i;
+        if (l2 < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: tile_w must be a power of two in 1..64, got %d", value);
+        st->tile_w_log2 = l2;
+        return LRT_OK;
+    }
+    LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: unknown option '%s'", name);
+}
+
+int lrt_enable_stats(lrt_state* st, int enable)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_enable_stats: null state");
+    st->stats_enabled = enable ? 1 : 0;
+    return LRT_OK;
+}
+
+int lrt_get_stats(lrt_state* st, uint64_t out[8], void* stream_)
+{
+    if (!st || !out) LRT_FAIL(LRT_ERR_ARG, "lrt_get_stats: null argument");
+    DeviceGuard dg(st->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipStreamSynchronize(stream));
+    unsigned long long h[8];
+    HIPCHK(hipMemcpy(h, st->stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = h[i];
+    HIPCHK(hipMemset(st->stats, 0, sizeof(h)));
+    return LRT_OK;
+}
+
+int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rots,
+              const float* opac, float mod, void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_build: null state");
+    if (P < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_build: negative P");
+    if (P > 0 && (!means || !scales || !rots || !opac)) LRT_FAIL(LRT_ERR_ARG, "lrt_build: null parameter pointer");
+    if (P >= (1 << 28)) LRT_FAIL(LRT_ERR_ARG, "lrt_build: P too large");
+    DeviceGuard dg(st->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = ensure_capacity(st, P, stream);
+    if (rc) return rc;
+    st->P = -1;
+    const int TB = 256;
+    if (P > 0) {
+        HIPCHK(hipMemsetAsync(st->bounds, 0xff, 3 * sizeof(unsigned), stream));
+        HIPCHK(hipMemsetAsync(st->bounds + 3, 0x00, 3 * sizeof(unsigned), stream));
+        int gb = (P + TB - 1) / TB; if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, st->bounds);
+        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, st->bounds, st->keys_a, st->vals_a);
+        size_t tmp = st->sort_tmp_bytes;
+        // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
+        HIPCHK(rocprim::radix_sort_pairs(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 24, 63, stream));
+        hipLaunchKernelGGL(k_make_records, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
+    }
+    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
+    int total = tree_layout(P, &nl, &L, cnt, off);
+    if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
+    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes);
+    for (int l = 2; l <= L; l++)
+        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes);
+    HIPCHK(hipGetLastError());
+    st->P = P; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
+    return LRT_OK;
+}
+
+static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t stream)
+{
+    const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
+    tp.tw_log2 = st->tile_w_log2;
+    tp.tiles_x = (tp.W + TW - 1) / TW;
+    const int tiles_y = (tp.H + TH - 1) / TH;
+    tp.n_tiles = tp.tiles_x * tiles_y;
+    tp.rec = st->rec; tp.nodes = st->nodes; tp.tile_counter = st->tile_counter;
+    tp.stats = st->stats_enabled ? st->stats : nullptr;
+    tp.nsh = (tp.deg + 1) * (tp.deg + 1);
+    if (tp.n_tiles == 0) return LRT_OK;
+    HIPCHK(hipMemsetAsync(st->tile_counter, 0, sizeof(unsigned), stream));
+    int blocks = (tp.n_tiles + 3) / 4;
+    if (blocks > 256 * 3) blocks = 256 * 3;                       // persistent: <= 3 blocks (12 waves) per CU
+    if (bwd) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
+    else     hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+static int check_common(const char* fn, lrt_state* st, int H, int W, int P, int M, int deg)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "%s: null state", fn);
+    if (st->P < 0) LRT_FAIL(LRT_ERR_STATE, "%s: no acceleration structure (call lrt_build first)", fn);
+    if (st->P != P) LRT_FAIL(LRT_ERR_STATE, "%s: P=%d does not match the built structure (P=%d)", fn, P, st->P);
+    if (H < 0 || W < 0) LRT_FAIL(LRT_ERR_ARG, "%s: negative image size", fn);
+    if (deg < 0 || deg > 3) LRT_FAIL(LRT_ERR_ARG, "%s: sh_degree must be in 0..3, got %d", fn, deg);
+    if (P > 0 && (deg + 1) * (deg + 1) > M) LRT_FAIL(LRT_ERR_ARG, "%s: sh_degree %d needs %d coefficients, shs has M=%d", fn, deg, (deg + 1) * (deg + 1), M);
+    return LRT_OK;
+}
+
+int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                const float* shs, const float* bg, int training, float* out9, int32_t* out_i32, float* accum,
+                void* stream_)
+{
+    (void)training;
+    int rc = check_common("lrt_forward", st, H, W, P, M, deg);
+    if (rc) return rc;
+    if ((size_t)H * W > 0 && (!ray_o || !ray_d || !out9)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null ray/output pointer");
+    if (!bg) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null background pointer");
+    if (P > 0 && (!shs || !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null shs/accum pointer");
+    DeviceGuard dg(st->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P > 0) HIPCHK(hipMemsetAsync(accum, 0, (size_t)P * sizeof(float), stream));
+    if (out_i32 && (size_t)H * W > 0)
+        hipLaunchKernelGGL(k_fill_i32, dim3((H * W + 255) / 256), dim3(256), 0, stream, H * W, -1, out_i32);
+    TraceParams tp; memset(&tp, 0, sizeof(tp));
+    tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
+    tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
+    return launch_trace(st, tp, false, stream);
+}
+
+int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                 const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
+                 const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
+                 float* d_opac, float* d_scales, float* d_rots, void* stream_)
+{
+    int rc = check_common("lrt_backward", st, H, W, P, M, deg);
+    if (rc) return rc;
+    if ((size_t)H * W > 0 && (!ray_o || !ray_d || !out9 || !dL_dout9)) LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null ray/output pointer");
+    if (!bg) LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null background pointer");
+    if (P > 0 && (!means || !scales || !rots || !opac || !shs || !d_means || !d_shs || !d_opac || !d_scales || !d_rots))
+        LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null parameter/gradient pointer");
+    DeviceGuard dg(st->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P > 0) {   // trace_surfels.cpp:322-329: gradients start from zero
+        HIPCHK(hipMemsetAsync(d_means, 0, (size_t)P * 3 * sizeof(float), stream));
+        HIPCHK(hipMemsetAsync(d_shs, 0, (size_t)P * M * 3 * sizeof(float), stream));
+        HIPCHK(hipMemsetAsync(d_opac, 0, (size_t)P * sizeof(float), stream));
+        HIPCHK(hipMemsetAsync(d_scales, 0, (size_t)P * 2 * sizeof(float), stream));
+        HIPCHK(hipMemsetAsync(d_rots, 0, (size_t)P * 4 * sizeof(float), stream));
+    }
+    TraceParams tp; memset(&tp, 0, sizeof(tp));
+    tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
+    tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg;
+    tp.means = means; tp.scales = scales; tp.rots = rots; tp.opac = opac; tp.mod = st->mod;
+    tp.out9_in = out9; tp.dL_dout = dL_dout9;
+    tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
+    return launch_trace(st, tp, true, stream);
+}
+
+}  // extern "C"

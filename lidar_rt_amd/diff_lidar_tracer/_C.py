@@ -1,0 +1,216 @@
+"""Counterpart of the reference's pybind module ``diff_lidar_tracer._C``
+(DLT/ext.cpp:18-23): the same four names, argument orders and return tuples,
+implemented on liblrt_hip.so through ctypes.
+
+    OptiXStateWrapper(pkg_dir)                           DLT/optix_tracer/optix_wrapper.cpp:177-233
+    build_acceleration_structure(state, vertices, triangles, rebuild)   DLT/trace_surfels.cpp:46-148
+    trace_surfels(state, training, ray_o, ray_d, vertices, background, means3D, shs, degree,
+                  colors_precomp, opacities, scales, scale_modifier, rotations, transMat_precomp,
+                  viewmatrix, projmatrix, campos, prefiltered, debug)
+                  -> (out_attr_float32 (H,W,9), out_attr_uint32 (H,W,1) int32 = -1, accum (P,))
+                                                                         DLT/trace_surfels.cpp:152-265
+    trace_surfels_backward(state, ray_o, ..., debug, out_attr_float32, out_attr_uint32, dL_dout)
+                  -> (dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
+                      dL_dtransMat_precomp, dL_dgrads3D_abs)              DLT/trace_surfels.cpp:269-386
+
+Difference by design: the acceleration structure is a software LBVH over the
+Gaussians' quads, derived on the device from (means, scales, rotations,
+opacities) -- exactly the quads ``build2DRectangle`` would produce.  The
+``vertices`` / ``triangles`` tensors are validated and remembered but not read
+by the kernels; ``build_acceleration_structure`` marks the structure dirty and
+``trace_surfels`` (re)builds it from the parameters it is given.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _capi
+
+
+class OptiXStateWrapper:
+    """Tracer state (LBVH buffers, workspace) bound to one device.  The name is
+    kept for drop-in compatibility; nothing here uses OptiX."""
+
+    def __init__(self, pkg_dir: str = ""):
+        self.pkg_dir = pkg_dir
+        self._lib = _capi.load()
+        self._handles = {}          # device index -> lrt_state*
+        self._dirty = {}            # device index -> bool
+        self._built_P = {}
+        self.stats_enabled = False
+        self.options = {}
+
+    def handle(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("diff_lidar_tracer: tensors must be on a HIP (cuda) device; there is no CPU path")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            h = self._lib.lrt_create(idx)
+            if not h:
+                raise _capi.LrtError("lrt_create failed: " + self._lib.lrt_last_error().decode())
+            self._handles[idx] = h
+            self._dirty[idx] = True
+            if self.stats_enabled:
+                self._lib.lrt_enable_stats(h, 1)
+            for k, v in self.options.items():
+                _capi.check(self._lib.lrt_set_option(h, k.encode(), int(v)), "lrt_set_option")
+        return idx, h
+
+    def mark_dirty(self):
+        for k in self._dirty:
+            self._dirty[k] = True
+        self._any_dirty = True
+
+    def set_option(self, name: str, value: int):
+        self.options[name] = int(value)
+        for h in self._handles.values():
+            _capi.check(self._lib.lrt_set_option(h, name.encode(), int(value)), "lrt_set_option")
+
+    def enable_stats(self, enable: bool = True):
+        self.stats_enabled = bool(enable)
+        for h in self._handles.values():
+            self._lib.lrt_enable_stats(h, 1 if enable else 0)
+
+    def get_stats(self, device=None):
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        arr = (C.c_uint64 * 8)()
+        with torch.cuda.device(idx):
+            s = torch.cuda.current_stream().cuda_stream
+            _capi.check(self._lib.lrt_get_stats(h, arr, C.c_void_p(s)), "lrt_get_stats")
+        names = ("candidates", "composited", "passes", "nodes_visited", "prims_tested")
+        return {n: int(arr[i]) for i, n in enumerate(names)}
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                self._lib.lrt_destroy(h)
+            self._handles = {}
+        except Exception:
+            pass
+
+
+def _check_f32_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")           # AT_ASSERTM(is_cuda), trace_surfels.cpp:33-35
+    if t.numel() > 0 and t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+
+
+def _stream_ptr():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def build_acceleration_structure(state: OptiXStateWrapper, vertices: torch.Tensor, triangles: torch.Tensor,
+                                 rebuild: int = 1) -> None:
+    # shape checks and messages of DLT/trace_surfels.cpp:53-58
+    if vertices.ndimension() != 2 or vertices.size(1) != 3:
+        raise RuntimeError("vertices must have dimensions (num_vertices, 3)")
+    if triangles.ndimension() != 2 or triangles.size(1) != 3:
+        raise RuntimeError("triangles must have dimensions (num_triangles, 3)")
+    if not vertices.is_cuda or not triangles.is_cuda:
+        raise RuntimeError("vertices/triangles must be CUDA tensors")
+    state.mark_dirty()
+    state.handle(vertices.device)      # create the per-device state eagerly (errors surface here)
+
+
+def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, opacities, scale_modifier=1.0):
+    """Fused fast path: LBVH straight from the Gaussian parameters (no vertices tensor)."""
+    for t, n in ((means3D, "means3D"), (scales, "scales"), (rotations, "rotations"), (opacities, "opacities")):
+        _check_f32_cuda(t, n)
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = means3D.size(0)
+    if scales.numel() != 2 * P or rotations.numel() != 4 * P or opacities.numel() != P:
+        raise RuntimeError("scales (P,2), rotations (P,4), opacities (P,1) must match means3D (P,3)")
+    idx, h = state.handle(means3D.device)
+    m, s, r, o = (means3D.detach().contiguous(), scales.detach().contiguous(), rotations.detach().contiguous(),
+                  opacities.detach().contiguous())
+    with torch.cuda.device(idx):
+        _capi.check(state._lib.lrt_build(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
+                                         float(scale_modifier), _stream_ptr()), "lrt_build")
+    state._dirty[idx] = False
+    state._built_P[idx] = P
+    # keep the inputs alive until the stream has consumed them (stream-ordered, no sync)
+    state._keep = (m, s, r, o)
+
+
+def _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+          transMat_precomp):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")     # trace_surfels.cpp:178-180
+    for t, n in ((ray_o, "ray_o"), (ray_d, "ray_d"), (background, "background"), (means3D, "means3D"),
+                 (shs, "shs"), (opacities, "opacities"), (scales, "scales"), (rotations, "rotations")):
+        _check_f32_cuda(t, n)
+    if colors_precomp is not None and colors_precomp.numel() > 0:
+        raise NotImplementedError("colors_precomp is not supported (the reference forward kernel ignores it and "
+                                  "reads shs unconditionally, forward.cu:261-263); pass shs")
+    if transMat_precomp is not None and transMat_precomp.numel() > 0:
+        raise NotImplementedError("cov3Ds_precomp / transMat_precomp is not supported (unused by the reference kernels)")
+    if ray_o.ndimension() != 3 or ray_o.size(2) != 3 or ray_d.shape != ray_o.shape:
+        raise RuntimeError("ray_o and ray_d must have dimensions (H, W, 3)")
+    P = means3D.size(0)
+    if P > 0 and (shs.ndimension() != 3 or shs.size(0) != P or shs.size(2) != 3):
+        raise RuntimeError("shs must have dimensions (num_points, M, 3)")
+    return P
+
+
+def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertices, background, means3D, shs,
+                  degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
+                  transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool):
+    P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+              transMat_precomp)
+    H, W = ray_o.size(0), ray_o.size(1)
+    M = shs.size(1) if shs.numel() > 0 else 0
+    dev = means3D.device
+    idx, h = state.handle(dev)
+    if state._dirty.get(idx, True) or state._built_P.get(idx, -1) != P:
+        build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier)
+    ro, rd = ray_o.detach().contiguous(), ray_d.detach().contiguous()      # ray_o is an expanded view upstream
+    bg = background.detach().contiguous()
+    sh = shs.detach().contiguous()
+    out = torch.empty((H, W, 9), dtype=torch.float32, device=dev)
+    out_i = torch.empty((H, W, 1), dtype=torch.int32, device=dev)
+    accum = torch.empty((P,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(idx):
+        _capi.check(state._lib.lrt_forward(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
+                                           _capi.ptr(sh), _capi.ptr(bg), 1 if training else 0, _capi.ptr(out),
+                                           _capi.ptr(out_i), _capi.ptr(accum), _stream_ptr()), "lrt_forward")
+    return out, out_i, accum
+
+
+def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, background, means3D, shs,
+                           degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
+                           transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32):
+    P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+              transMat_precomp)
+    H, W = ray_o.size(0), ray_o.size(1)
+    M = shs.size(1) if shs.numel() > 0 else 0
+    dev = means3D.device
+    idx, h = state.handle(dev)
+    if state._built_P.get(idx, -1) != P:
+        raise RuntimeError("trace_surfels_backward: acceleration structure does not match (run forward first)")
+    ro, rd = ray_o.detach().contiguous(), ray_d.detach().contiguous()
+    bg = background.detach().contiguous()
+    m, s, r, o, sh = (means3D.detach().contiguous(), scales.detach().contiguous(), rotations.detach().contiguous(),
+                      opacities.detach().contiguous(), shs.detach().contiguous())
+    out = out_attr_float32.detach().contiguous()
+    dL = dL_dout_attr_float32.detach().contiguous().to(torch.float32)
+    opts = dict(dtype=torch.float32, device=dev)
+    d_means = torch.empty((P, 3), **opts); d_shs = torch.empty((P, M, 3), **opts)
+    d_opac = torch.empty((P, 1), **opts); d_scales = torch.empty((P, 2), **opts); d_rot = torch.empty((P, 4), **opts)
+    with torch.cuda.device(idx):
+        _capi.check(state._lib.lrt_backward(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
+                                            _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o), _capi.ptr(sh),
+                                            _capi.ptr(bg), _capi.ptr(out), _capi.ptr(dL), _capi.ptr(d_means),
+                                            _capi.ptr(d_shs), _capi.ptr(d_opac), _capi.ptr(d_scales),
+                                            _capi.ptr(d_rot), _stream_ptr()), "lrt_backward")
+    # dead outputs of the reference (never written by backward.cu): returned as zeros
+    d_colors = torch.zeros((P, 3), **opts)
+    d_trans = torch.zeros((P, 9), **opts)
+    d_g3abs = torch.zeros((P, 3), **opts)
+    return d_means, d_shs, d_colors, d_opac, d_scales, d_rot, d_trans, d_g3abs
