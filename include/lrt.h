@@ -87,6 +87,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
 int lrt_enable_stats(lrt_state* st, int enable);
 int lrt_get_stats(lrt_state* st, uint64_t stats_out[8], void* stream);
 
+/* Debug/test hook: copy an internal buffer of the current build to the host (see lrt_kernels.hip). */
+long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max_bytes, void* stream);
+
 /* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays). */
 int lrt_set_option(lrt_state* st, const char* name, int value);
 

@@ -29,7 +29,9 @@
 #define LRT_LEAF 8            // primitives per leaf (tested exhaustively by the packet)
 #define LRT_NODE_FLOATS 64    // 48 box floats (SoA lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]) + header, 256 B
 #define LRT_MAX_LEVELS 12
-#define LRT_INF __int_as_float(0x7f800000)
+// An EMPTY child slot is stored as the degenerate box [1e30,1e30]^3: a min/max slab test treats an inverted box
+// (lo > hi) as the huge box [hi, lo] and would descend into it, a far-away point is never reached (|t| >= 1e30).
+#define LRT_EMPTY 1e30f
 
 static thread_local char g_err[512] = "";
 #define LRT_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
@@ -54,6 +56,8 @@ struct lrt_state {
     int stats_enabled;
     int tile_w_log2;
     int n_nodes, n_leaves;
+    int no_cull;         // debug: visit every non-empty child (no ray/box culling)
+    float* dbg; size_t dbg_floats;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -137,7 +141,8 @@ __global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __res
         for (int i = 0; i < 3; i++) { lo[i] = fminf(lo[i], a[i]); hi[i] = fmaxf(hi[i], a[3 + i]); }
     }
     float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
-    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = lo[i]; nd[24 + i * 8 + c] = hi[i]; }
+    const bool empty = lo[0] > hi[0];
+    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(j * 8); nd[49] = __int_as_float(1); }   // children = leaves, base leaf 8j
 }
 
@@ -151,11 +156,14 @@ __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, f
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     if (ch < n_child) {
         const float* cn = nodes + (size_t)(child_off + ch) * LRT_NODE_FLOATS;
-        for (int i = 0; i < 3; i++)
-            for (int e = 0; e < 8; e++) { lo[i] = fminf(lo[i], cn[i * 8 + e]); hi[i] = fmaxf(hi[i], cn[24 + i * 8 + e]); }
+        for (int e = 0; e < 8; e++) {
+            if (cn[e] >= LRT_EMPTY) continue;                   // empty grandchild
+            for (int i = 0; i < 3; i++) { lo[i] = fminf(lo[i], cn[i * 8 + e]); hi[i] = fmaxf(hi[i], cn[24 + i * 8 + e]); }
+        }
     }
     float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
-    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = lo[i]; nd[24 + i * 8 + c] = hi[i]; }
+    const bool empty = lo[0] > hi[0];
+    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(child_off + j * 8); nd[49] = __int_as_float(0); }
 }
 
@@ -163,7 +171,7 @@ __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, f
 // Trace
 struct TraceParams {
     int H, W, P, M, deg, nsh;
-    int tw_log2, tiles_x, n_tiles;
+    int tw_log2, tiles_x, n_tiles, no_cull;
     const float* ray_o; const float* ray_d;
     const float* rec; const float* nodes;
     const float* shs; const float* bg;
@@ -174,6 +182,7 @@ struct TraceParams {
     float* d_means; float* d_shs; float* d_opac; float* d_scales; float* d_rots;
     unsigned* tile_counter;
     unsigned long long* stats;
+    float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
 };
 
 #define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
@@ -215,6 +224,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
         }
         float base = __uint_as_float(__float_as_uint(LRT_T_NEAR) - 1u);   // accept t >= 0.2 (forward.cu:214)
         bool done = !valid;
+        int dbg_n = 0;
 
         for (int pass = 0; pass < 4096; ++pass) {   // hard bound (65k hits per ray) so a bug can never hang the GPU
             const bool act = !done;
@@ -271,13 +281,13 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                         const float t0z = (nd[16 + c] - o[2]) * inv[2], t1z = (nd[40 + c] - o[2]) * inv[2];
                         const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
                         const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                        const bool hit = act && (tf >= fmaxf(tn, base)) && (tn <= tfar);
+                        const bool hit = (p.no_cull & 1) ? (nd[c] < LRT_EMPTY) : (act && (tf >= fmaxf(tn, base)) && (tn <= tfar));
                         const unsigned long long m = __ballot(hit);
                         unsigned kk = 0xffffffffu;
                         if (m) {
                             const int first = __ffsll((long long)m) - 1;
                             const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tn, 0.f)), first);
-                            kk = (kb & ~7u) | (unsigned)c;
+                            kk = (p.no_cull & 2) ? (unsigned)c : ((kb & ~7u) | (unsigned)c);
                             nh++;
                         }
                         key[c] = kk;
@@ -312,6 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                 if (on) {
                     const float t = s_t[wv][i][lane]; const int g = s_g[wv][i][lane]; const float ao = s_a[wv][i][lane];
                     last_t = t;
+                    if (p.dbg && dbg_n < 32) { p.dbg[r * 64 + 2 * dbg_n] = t; p.dbg[r * 64 + 2 * dbg_n + 1] = __int_as_float(g); dbg_n++; }
                     st_cand++;
                     const float alpha = fminf(LRT_ALPHA_MAX, ao);                       // forward.cu:247
                     if (alpha >= LRT_ALPHA_MIN) {
@@ -511,6 +522,13 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->tile_w_log2 = l2;
         return LRT_OK;
     }
+    if (!strcmp(name, "no_cull")) { st->no_cull = value; return LRT_OK; }   // debug bits: 1 = no box culling, 2 = no child ordering
+    if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
+        DeviceGuard dg(st->device);
+        if (st->dbg) { (void)hipFree(st->dbg); st->dbg = nullptr; st->dbg_floats = 0; }
+        if (value > 0) { HIPCHK(hipMalloc(&st->dbg, (size_t)value * 64 * sizeof(float))); st->dbg_floats = (size_t)value * 64; }
+        return LRT_OK;
+    }
     LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: unknown option '%s'", name);
 }
 
@@ -532,6 +550,28 @@ int lrt_get_stats(lrt_state* st, uint64_t out[8], void* stream_)
     for (int i = 0; i < 8; i++) out[i] = h[i];
     HIPCHK(hipMemset(st->stats, 0, sizeof(h)));
     return LRT_OK;
+}
+
+/* Debug/test hook (not part of the drop-in surface): copy an internal buffer of the current build to the host.
+ * which: 0 = sorted order (P x u32), 1 = records (P x 16 f32), 2 = nodes (n_nodes x 64 f32), 3 = aabbs (P x 6 f32).
+ * Returns the number of bytes available (copies min(available, max_bytes)); synchronises `stream`. */
+long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max_bytes, void* stream_)
+{
+    if (!st || st->P < 0) LRT_FAIL(LRT_ERR_STATE, "lrt_debug_read: nothing built");
+    DeviceGuard dg(st->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+    const void* src = nullptr; long long bytes = 0;
+    switch (which) {
+        case 0: src = st->vals_b; bytes = (long long)st->P * 4; break;
+        case 1: src = st->rec; bytes = (long long)st->P * LRT_REC_FLOATS * 4; break;
+        case 2: src = st->nodes; bytes = (long long)st->n_nodes * LRT_NODE_FLOATS * 4; break;
+        case 3: src = st->aabb; bytes = (long long)st->P * 6 * 4; break;
+        case 4: src = st->dbg; bytes = (long long)st->dbg_floats * 4; break;
+        default: LRT_FAIL(LRT_ERR_ARG, "lrt_debug_read: unknown buffer %d", which);
+    }
+    long long n = bytes < max_bytes ? bytes : max_bytes;
+    if (n > 0 && host_dst) HIPCHK(hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    return bytes;
 }
 
 int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rots,
@@ -576,7 +616,9 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     tp.tiles_x = (tp.W + TW - 1) / TW;
     const int tiles_y = (tp.H + TH - 1) / TH;
     tp.n_tiles = tp.tiles_x * tiles_y;
-    tp.rec = st->rec; tp.nodes = st->nodes; tp.tile_counter = st->tile_counter;
+    tp.rec = st->rec; tp.nodes = st->nodes; tp.tile_counter = st->tile_counter; tp.no_cull = st->no_cull;
+    tp.dbg = (!bwd && st->dbg && st->dbg_floats >= (size_t)tp.H * tp.W * 64) ? st->dbg : nullptr;
+    if (tp.dbg) HIPCHK(hipMemsetAsync(tp.dbg, 0, (size_t)tp.H * tp.W * 64 * sizeof(float), stream));
     tp.stats = st->stats_enabled ? st->stats : nullptr;
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
