@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LiDAR Gaussian tracer.
+
+Metric (BASELINE.json): LiDAR rays/s, forward + backward, 1 M Gaussians, 2048x64 sweep (workload S1M,
+SURVEY.md section 8(d)); reported with the HBM-roofline fraction of the dominant kernel and with the CPU
+oracle timed beside it.
+
+One STEP = what the reference does once per training iteration for this operator
+(lib/gaussian_renderer/__init__.py:142-160 + loss.backward()):
+    acceleration-structure rebuild (fused build2DRectangle + LBVH)  ->  trace_surfels  ->  trace_surfels_backward
+on inputs already resident in HBM.  With N > 1 the frame is sharded by azimuth sector (strong scaling: the
+frame is fixed), slabs are all-gathered and the fused gradient buffer is all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from lidar_rt_amd import scenes  # noqa: E402
+
+HBM_PEAK_BYTES_PER_S = 8.0e12        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3e12 achievable
+
+
+def algorithmic_bytes(C: float, K: float, deg: int = 3):
+    """SURVEY.md section 8(d) byte model, per ray: (forward, backward)."""
+    n = 12 * (deg + 1) ** 2
+    fwd = 24 + 36 + 40 * C + (n + 8) * K
+    bwd = 24 + 36 + 36 + 40 * C + (n + 2 * (40 + n)) * K
+    return fwd, bwd
+
+
+def cpu_baseline(sc, ray_o, ray_d, deg, bg, dL, col_stride=8):
+    """Oracle ("port") on all host cores, on every `col_stride`-th column of the same frame."""
+    from oracle import oracle
+    ncores = oracle.num_threads()
+    o = np.ascontiguousarray(ray_o[:, ::col_stride]); d = np.ascontiguousarray(ray_d[:, ::col_stride])
+    g = np.ascontiguousarray(dL[:, ::col_stride])
+    t0 = time.time()
+    orc = oracle.Oracle(sc["means"], sc["scales"], sc["rotations"], sc["opacities"], "f32")
+    t1 = time.time()
+    fw = orc.forward(o, d, sc["shs"], deg, bg)
+    t2 = time.time()
+    orc.backward(o, d, sc["shs"], deg, bg, fw["out"], g)
+    t3 = time.time()
+    n = o.shape[0] * o.shape[1]
+    return {"value": n / (t3 - t1), "unit": "rays/s", "cores": ncores, "kind": "port",
+            "sample": f"every {col_stride}th azimuth column of the S1M frame ({o.shape[0]}x{o.shape[1]} = {n} rays), "
+                      f"forward+backward, OpenMP over rays; BVH build {t1 - t0:.2f}s excluded; "
+                      f"fwd {t2 - t1:.2f}s bwd {t3 - t2:.2f}s",
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
+    ap.add_argument("--tile-w", type=int, default=0, help="rays per tile row (power of two, 0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    # ---------------- synthetic workload (identical on every rank: seeded)
+    if args.workload == "s1m":
+        sc, ro, rd = scenes.s1m(); wl = "S1M: 1,000,000 Gaussians, 64x2048 KITTI-style sweep (BASELINE configs[1])"
+    elif args.workload == "s200k":
+        sc = scenes.make_scene(200_000, radius_scale=0.5); ro, rd = scenes.kitti_rays(32, 512); wl = "S200k (dev)"
+    else:
+        sc, ro, rd = scenes.s10k(); wl = "S10k: 10,000 Gaussians, 16x256 rays (BASELINE configs[0])"
+    H, W = ro.shape[:2]
+    deg = 3
+    bg_np = scenes.BG_DEFAULT
+    dL_np = scenes.upstream_grad(H, W)
+    t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
+    ray_o, ray_d = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
+    bg = torch.as_tensor(bg_np, device=dev)
+    dL = torch.as_tensor(dL_np, device=dev)
+
+    from lidar_rt_amd.parallel import ShardedTracer
+    tr = ShardedTracer()
+    st = tr.backend.state
+    if args.tile_w:
+        st.set_option("tile_w", args.tile_w)
+
+    def step():
+        out, _ = tr.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg,
+                            rebuild=not args.no_build_in_step)
+        g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
+        return out, g
+
+    if args.no_build_in_step:
+        tr.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+    for _ in range(max(args.warmup, 0)):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    st.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    kt = st.get_timing(dev)
+    st.enable_timing(False)
+
+    # ---------------- one instrumented step for the traversal statistics (untimed)
+    st.enable_stats(True)
+    out, g = step()
+    torch.cuda.synchronize()
+    hs = st.get_stats(dev)
+    st.enable_stats(False)
+
+    if rank == 0:
+        n_rays = H * W
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_rays * args.steps / elapsed
+        # ---- roofline of the dominant kernel (per launch, this rank's slab)
+        a, b = tr._slab
+        rays_local = H * (b - a)
+        stats_path = os.path.join(REPO, "tests", "golden", "s1m_stats.json")
+        if args.workload == "s1m" and os.path.exists(stats_path):
+            gs = json.load(open(stats_path))
+            C, K = gs["C_mean_candidates_per_ray"], gs["K_mean_composited_per_ray"]
+            ck_src = "oracle (tests/golden/s1m_stats.json)"
+        else:
+            C = hs["candidates"] / 2.0 / max(rays_local, 1); K = hs["composited"] / 2.0 / max(rays_local, 1)
+            ck_src = "HIP counters of this run"
+        bf, bb = algorithmic_bytes(C, K, deg)
+        ms_f = kt["fwd"][0] / max(kt["fwd"][1], 1); ms_b = kt["bwd"][0] / max(kt["bwd"][1], 1)
+        ms_build = kt["build"][0] / max(kt["build"][1], 1)
+        dom = "k_trace<bwd>" if ms_b >= ms_f else "k_trace<fwd>"
+        dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
+                "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
+                "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b},
+                "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S}
+        res = {
+            "metric": "LiDAR rays/s fwd+bwd @1M Gaussians, 2048x64 sweep; % HBM roofline",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
+                       "step": ("LBVH rebuild + " if not args.no_build_in_step else "") + "forward + backward"
+                               + (" + slab all_gather + fused gradient all_reduce (RCCL)" if world > 1 else ""),
+                       "parallelism": f"azimuth-sector x{world}", "tile_w": args.tile_w or 16},
+            "roofline": roof,
+            "hip_counters_per_step": {k: v for k, v in hs.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(sc, ro, rd, deg, bg_np, dL_np)
+            except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
+                res["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

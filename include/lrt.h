@@ -87,6 +87,11 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
 int lrt_enable_stats(lrt_state* st, int enable);
 int lrt_get_stats(lrt_state* st, uint64_t stats_out[8], void* stream);
 
+/* HIP-event timing on the caller's stream: index 0 = whole lrt_build region, 1 = forward trace kernel,
+ * 2 = backward trace kernel.  lrt_get_timing synchronises `stream`, returns summed ms + launch counts, resets. */
+int lrt_enable_timing(lrt_state* st, int enable);
+int lrt_get_timing(lrt_state* st, double ms_sum[4], int count[4], void* stream);
+
 /* Debug/test hook: copy an internal buffer of the current build to the host (see lrt_kernels.hip). */
 long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max_bytes, void* stream);
 

@@ -20,6 +20,8 @@
 #include <string.h>
 #include <cstring>
 
+#include <vector>
+
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -58,6 +60,10 @@ struct lrt_state {
     int n_nodes, n_leaves;
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
+    // HIP-event timing of the build region and of each trace kernel, on the caller's stream
+    int timing_enabled;
+    struct TimerSlot { hipEvent_t a, b; int kind; };
+    std::vector<TimerSlot>* timers; size_t timers_used;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -65,6 +71,7 @@ struct lrt_state {
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
+__device__ __forceinline__ float rdl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ unsigned wave_sum_u(unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
@@ -114,7 +121,14 @@ __global__ void k_make_records(int P, const uint32_t* __restrict__ order, const 
                                float* __restrict__ aabb)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
+    const int Ppad = (P + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
+    if (k >= Ppad) return;
+    if (k >= P) {                                   // padding so that every leaf holds LRT_LEAF records
+        float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
+        dst[0] = make_float4(0.f, 0.f, 1.f, -1.f); dst[1] = make_float4(0.f, 0.f, 0.f, -1.f);
+        dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     int g = (int)order[k];
     float mu[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float sc[2] = {scales[2 * g], scales[2 * g + 1]};
@@ -171,7 +185,7 @@ __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, f
 // Trace
 struct TraceParams {
     int H, W, P, M, deg, nsh;
-    int tw_log2, tiles_x, n_tiles, no_cull;
+    int tw_log2, tiles_x, tiles_y, n_tiles, no_cull;
     const float* ray_o; const float* ray_d;
     const float* rec; const float* nodes;
     const float* shs; const float* bg;
@@ -200,14 +214,26 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
     const int TH = 64 >> p.tw_log2;
     const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
     const int nsh = p.nsh;
-    unsigned st_cand = 0, st_comp = 0, st_pass = 0, st_nodes = 0, st_prims = 0;
+    unsigned st_cand = 0, st_comp = 0, st_pass = 0, st_nodes = 0, st_prims = 0, st_ins = 0;
+    unsigned long long st_clk_sum = 0, st_clk_max = 0;
 
+    // Persistent wavefronts with XCD-aware work distribution: the tile grid is cut into 8 contiguous azimuth
+    // sectors, one queue per XCD (workgroup b is observed to run on XCD b % 8 -- used for L2 locality only, any
+    // placement is correct).  A wave drains its own XCD's queue first, then steals from the others.
+    unsigned q = blockIdx.x & 7u; int q_tried = 0;
     for (;;) {
-        unsigned tile = 0;
-        if (lane == 0) tile = atomicAdd(p.tile_counter, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= (unsigned)p.n_tiles) break;
-        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int c0 = (int)(q * (unsigned)p.tiles_x) >> 3, c1 = (int)((q + 1u) * (unsigned)p.tiles_x) >> 3;
+        const unsigned nq = (unsigned)((c1 - c0) * p.tiles_y);
+        unsigned ti = 0;
+        if (lane == 0) ti = atomicAdd(p.tile_counter + q, 1u);
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        if (ti >= nq) {
+            if (++q_tried == 8) break;
+            q = (q + 1u) & 7u;
+            continue;
+        }
+        const int ty = (int)(ti % (unsigned)p.tiles_y), tx = c0 + (int)(ti / (unsigned)p.tiles_y);
+        const unsigned long long clk0 = p.stats ? wall_clock64() : 0ull;
         const int h = ty * TH + (lane >> p.tw_log2), w = (tx << p.tw_log2) + (lane & TWm);
         const bool valid = (h < p.H) && (w < p.W);
         const size_t r = valid ? ((size_t)h * p.W + w) : 0;
@@ -243,16 +269,27 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                 sp--;
                 const unsigned e = (unsigned)__builtin_amdgcn_readlane(stk, sp);
                 if (e & 0x80000000u) {
-                    // ---------------- leaf: every ray of the tile tests every quad of the leaf
+                    // ---------------- leaf: every ray of the tile tests every quad of the leaf.
+                    // ONE coalesced 512-B vector load fetches the 8 records (lane L holds float4 #L%4 of quad L/4);
+                    // each record is then broadcast to SGPRs with v_readlane (one memory round trip per leaf, not per quad).
                     const int k0 = (int)(e & 0x7fffffffu) * LRT_LEAF;
-                    const int k1 = min(k0 + LRT_LEAF, p.P);
-                    for (int k = k0; k < k1; ++k) {
-                        const float* rc = g_rec + (size_t)k * LRT_REC_FLOATS;     // wave-uniform -> scalar loads
+                    float4 lv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < 4 * LRT_LEAF) lv = reinterpret_cast<const float4*>(g_rec)[(size_t)k0 * 4 + lane];
+                    for (int j = 0; j < LRT_LEAF; ++j) {
+                        const int l0 = 4 * j;
+                        float rc[LRT_REC_FLOATS];
+                        rc[7] = rdl(lv.w, l0 + 1);
+                        if (!(rc[7] > 0.f)) continue;                                   // unhittable / padding record
+                        rc[0] = rdl(lv.x, l0); rc[1] = rdl(lv.y, l0); rc[2] = rdl(lv.z, l0); rc[3] = rdl(lv.w, l0);
+                        rc[4] = rdl(lv.x, l0 + 1); rc[5] = rdl(lv.y, l0 + 1); rc[6] = rdl(lv.z, l0 + 1);
+                        rc[8] = rdl(lv.x, l0 + 2); rc[9] = rdl(lv.y, l0 + 2); rc[10] = rdl(lv.z, l0 + 2); rc[11] = rdl(lv.w, l0 + 2);
+                        rc[12] = rdl(lv.x, l0 + 3); rc[13] = rdl(lv.y, l0 + 3); rc[14] = rdl(lv.z, l0 + 3); rc[15] = 0.f;
                         float t, ao;
                         bool hit = lrt_splat_hit(rc, o, d, &t, &ao);
                         hit = hit && act && (t > base) && (t < kt[LRT_CHUNK - 1]);   // anyhit: forward.cu:323
                         st_prims++;
                         if (__any(hit)) {
+                            st_ins++;
                             if (hit) {
                                 cnt++;
                                 float ct = t, ca = ao; int cg = __float_as_int(rc[11]);
@@ -268,9 +305,15 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                     }
                 } else {
                     // ---------------- inner node: 8 child boxes (SoA), slab test per lane, ballot per child
-                    const float* nd = g_nodes + (size_t)e * LRT_NODE_FLOATS;       // wave-uniform
-                    const unsigned cbase = (unsigned)__float_as_int(nd[48]);
-                    const unsigned cleaf = (unsigned)__float_as_int(nd[49]) << 31;
+                    typedef float f16v __attribute__((ext_vector_type(16)));
+                    const f16v* ndv = static_cast<const f16v*>(__builtin_assume_aligned(g_nodes + (size_t)e * LRT_NODE_FLOATS, 256));
+                    const f16v nA = ndv[0], nB = ndv[1], nC = ndv[2];               // 3 x s_load_dwordx16: lo.x lo.y | lo.z hi.x | hi.y hi.z
+                    const float2 nH = *reinterpret_cast<const float2*>(g_nodes + (size_t)e * LRT_NODE_FLOATS + 48);
+                    float nd[48];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { nd[i] = nA[i]; nd[16 + i] = nB[i]; nd[32 + i] = nC[i]; }
+                    const unsigned cbase = (unsigned)__float_as_int(nH.x);
+                    const unsigned cleaf = (unsigned)__float_as_int(nH.y) << 31;
                     const float tfar = kt[LRT_CHUNK - 1];
                     unsigned key[8]; int nh = 0;
                     st_nodes++;
@@ -404,6 +447,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
             }
         }
 
+        if (p.stats) { const unsigned long long dc = wall_clock64() - clk0; st_clk_sum += dc; st_clk_max = dc > st_clk_max ? dc : st_clk_max; }
         if (!BWD && valid) {
             float* op_ = p.out9 + LRT_NCH * r;
             op_[0] = C0 + T * bg0; op_[1] = C1 + T * bg1; op_[2] = C2 + T * bg2;
@@ -411,6 +455,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
         }
     }
     if (p.stats) {
+        if (lane == 0) { atomicAdd(p.stats + 5, st_clk_sum); atomicMax(p.stats + 6, st_clk_max); atomicAdd(p.stats + 7, (unsigned long long)st_ins); }
         const unsigned a = wave_sum_u(st_cand), c = wave_sum_u(st_comp);
         if (lane == 0) {
             atomicAdd(p.stats + 0, (unsigned long long)a); atomicAdd(p.stats + 1, (unsigned long long)c);
@@ -458,7 +503,7 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     for (void* q : olds) (void)hipFree(q);
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
-    HIPCHK(hipMalloc(&st->rec, cap * LRT_REC_FLOATS * sizeof(float)));
+    HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc(&st->aabb, cap * 6 * sizeof(float)));
     HIPCHK(hipMalloc(&st->keys_a, cap * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&st->keys_b, cap * sizeof(uint64_t)));
@@ -475,6 +520,23 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     st->capP = cap;
     return LRT_OK;
 }
+
+struct ScopedTimer {
+    lrt_state* st; hipStream_t stream; lrt_state::TimerSlot* slot = nullptr;
+    ScopedTimer(lrt_state* s, int kind, hipStream_t str) : st(s), stream(str)
+    {
+        if (!st->timing_enabled) return;
+        if (st->timers_used == st->timers->size()) {
+            lrt_state::TimerSlot t; t.kind = kind;
+            if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+            st->timers->push_back(t);
+        }
+        slot = &(*st->timers)[st->timers_used++];
+        slot->kind = kind;
+        (void)hipEventRecord(slot->a, stream);
+    }
+    ~ScopedTimer() { if (slot) (void)hipEventRecord(slot->b, stream); }
+};
 
 extern "C" {
 
@@ -493,6 +555,7 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
+    st->timers = new std::vector<lrt_state::TimerSlot>();
     if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
@@ -509,6 +572,8 @@ void lrt_destroy(lrt_state* st)
     DeviceGuard dg(st->device);
     void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->bounds, st->tile_counter, st->stats};
     for (void* q : olds) (void)hipFree(q);
+    for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    delete st->timers;
     delete st;
 }
 
@@ -530,6 +595,32 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         return LRT_OK;
     }
     LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: unknown option '%s'", name);
+}
+
+int lrt_enable_timing(lrt_state* st, int enable)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_enable_timing: null state");
+    st->timing_enabled = enable ? 1 : 0;
+    st->timers_used = 0;
+    return LRT_OK;
+}
+
+/* ms_sum[k], count[k] for k = 0 build region, 1 forward trace kernel, 2 backward trace kernel; resets the log. */
+int lrt_get_timing(lrt_state* st, double ms_sum[4], int count[4], void* stream_)
+{
+    if (!st || !ms_sum || !count) LRT_FAIL(LRT_ERR_ARG, "lrt_get_timing: null argument");
+    DeviceGuard dg(st->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+    for (int k = 0; k < 4; k++) { ms_sum[k] = 0.0; count[k] = 0; }
+    for (size_t i = 0; i < st->timers_used; i++) {
+        auto& t = (*st->timers)[i];
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(t.b));
+        HIPCHK(hipEventElapsedTime(&ms, t.a, t.b));
+        if (t.kind >= 0 && t.kind < 4) { ms_sum[t.kind] += ms; count[t.kind]++; }
+    }
+    st->timers_used = 0;
+    return LRT_OK;
 }
 
 int lrt_enable_stats(lrt_state* st, int enable)
@@ -586,6 +677,7 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     int rc = ensure_capacity(st, P, stream);
     if (rc) return rc;
     st->P = -1;
+    ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     if (P > 0) {
         HIPCHK(hipMemsetAsync(st->bounds, 0xff, 3 * sizeof(unsigned), stream));
@@ -596,7 +688,7 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
         size_t tmp = st->sort_tmp_bytes;
         // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
         HIPCHK(rocprim::radix_sort_pairs(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 24, 63, stream));
-        hipLaunchKernelGGL(k_make_records, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
+        hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
     int total = tree_layout(P, &nl, &L, cnt, off);
@@ -614,17 +706,18 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
     tp.tw_log2 = st->tile_w_log2;
     tp.tiles_x = (tp.W + TW - 1) / TW;
-    const int tiles_y = (tp.H + TH - 1) / TH;
-    tp.n_tiles = tp.tiles_x * tiles_y;
+    tp.tiles_y = (tp.H + TH - 1) / TH;
+    tp.n_tiles = tp.tiles_x * tp.tiles_y;
     tp.rec = st->rec; tp.nodes = st->nodes; tp.tile_counter = st->tile_counter; tp.no_cull = st->no_cull;
     tp.dbg = (!bwd && st->dbg && st->dbg_floats >= (size_t)tp.H * tp.W * 64) ? st->dbg : nullptr;
     if (tp.dbg) HIPCHK(hipMemsetAsync(tp.dbg, 0, (size_t)tp.H * tp.W * 64 * sizeof(float), stream));
     tp.stats = st->stats_enabled ? st->stats : nullptr;
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
-    HIPCHK(hipMemsetAsync(st->tile_counter, 0, sizeof(unsigned), stream));
+    HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
     int blocks = (tp.n_tiles + 3) / 4;
     if (blocks > 256 * 3) blocks = 256 * 3;                       // persistent: <= 3 blocks (12 waves) per CU
+    ScopedTimer tm(st, bwd ? 2 : 1, stream);
     if (bwd) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
     else     hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
     HIPCHK(hipGetLastError());

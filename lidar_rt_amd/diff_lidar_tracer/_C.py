@@ -53,6 +53,8 @@ class OptiXStateWrapper:
             self._dirty[idx] = True
             if self.stats_enabled:
                 self._lib.lrt_enable_stats(h, 1)
+            if getattr(self, "timing_enabled", False):
+                self._lib.lrt_enable_timing(h, 1)
             for k, v in self.options.items():
                 _capi.check(self._lib.lrt_set_option(h, k.encode(), int(v)), "lrt_set_option")
         return idx, h
@@ -80,8 +82,25 @@ class OptiXStateWrapper:
         with torch.cuda.device(idx):
             s = torch.cuda.current_stream().cuda_stream
             _capi.check(self._lib.lrt_get_stats(h, arr, C.c_void_p(s)), "lrt_get_stats")
-        names = ("candidates", "composited", "passes", "nodes_visited", "prims_tested")
+        names = ("candidates", "composited", "passes", "nodes_visited", "prims_tested", "tile_clk_sum", "tile_clk_max",
+                 "wave_inserts")
         return {n: int(arr[i]) for i, n in enumerate(names)}
+
+    def enable_timing(self, enable: bool = True):
+        self.timing_enabled = bool(enable)
+        for h in self._handles.values():
+            self._lib.lrt_enable_timing(h, 1 if enable else 0)
+
+    def get_timing(self, device=None):
+        """HIP-event timings since the last call: {'build'|'fwd'|'bwd': (sum_ms, count)}."""
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        ms = (C.c_double * 4)(); cnt = (C.c_int * 4)()
+        with torch.cuda.device(idx):
+            s = torch.cuda.current_stream().cuda_stream
+            _capi.check(self._lib.lrt_get_timing(h, ms, cnt, C.c_void_p(s)), "lrt_get_timing")
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(("build", "fwd", "bwd"))}
 
     def __del__(self):
         try:
