@@ -277,22 +277,27 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                     if (lane < 4 * LRT_LEAF) lv = reinterpret_cast<const float4*>(g_rec)[(size_t)k0 * 4 + lane];
                     for (int j = 0; j < LRT_LEAF; ++j) {
                         const int l0 = 4 * j;
-                        float rc[LRT_REC_FLOATS];
-                        rc[7] = rdl(lv.w, l0 + 1);
-                        if (!(rc[7] > 0.f)) continue;                                   // unhittable / padding record
-                        rc[0] = rdl(lv.x, l0); rc[1] = rdl(lv.y, l0); rc[2] = rdl(lv.z, l0); rc[3] = rdl(lv.w, l0);
-                        rc[4] = rdl(lv.x, l0 + 1); rc[5] = rdl(lv.y, l0 + 1); rc[6] = rdl(lv.z, l0 + 1);
-                        rc[8] = rdl(lv.x, l0 + 2); rc[9] = rdl(lv.y, l0 + 2); rc[10] = rdl(lv.z, l0 + 2); rc[11] = rdl(lv.w, l0 + 2);
-                        rc[12] = rdl(lv.x, l0 + 3); rc[13] = rdl(lv.y, l0 + 3); rc[14] = rdl(lv.z, l0 + 3); rc[15] = 0.f;
-                        float t, ao;
-                        bool hit = lrt_splat_hit(rc, o, d, &t, &ao);
-                        hit = hit && act && (t > base) && (t < kt[LRT_CHUNK - 1]);   // anyhit: forward.cu:323
+                        // staged test, cheapest rejection first; every stage ends in a wave-uniform early-out
+                        const float flim = rdl(lv.w, l0 + 1);
+                        if (!(flim > 0.f)) continue;                                    // unhittable / padding record
                         st_prims++;
+                        const float nx = rdl(lv.x, l0), ny = rdl(lv.y, l0), nz = rdl(lv.z, l0);
+                        const float cx = rdl(lv.x, l0 + 1) - o[0], cy = rdl(lv.y, l0 + 1) - o[1], cz = rdl(lv.z, l0 + 1) - o[2];
+                        const float t = (nx * cx + ny * cy + nz * cz) / (nx * d[0] + ny * d[1] + nz * d[2]);
+                        bool hit = act && (t > base) && (t < kt[LRT_CHUNK - 1]);         // anyhit: forward.cu:323
+                        if (!__any(hit)) continue;
+                        const float px = t * d[0] - cx, py = t * d[1] - cy, pz = t * d[2] - cz;   // x - mu
+                        const float u = rdl(lv.x, l0 + 2) * px + rdl(lv.y, l0 + 2) * py + rdl(lv.z, l0 + 2) * pz;
+                        hit = hit && (fabsf(u) <= flim);
+                        if (!__any(hit)) continue;
+                        const float v = rdl(lv.x, l0 + 3) * px + rdl(lv.y, l0 + 3) * py + rdl(lv.z, l0 + 3) * pz;
+                        hit = hit && (fabsf(v) <= flim);
                         if (__any(hit)) {
                             st_ins++;
                             if (hit) {
                                 cnt++;
-                                float ct = t, ca = ao; int cg = __float_as_int(rc[11]);
+                                float ct = t, ca = rdl(lv.w, l0) * expf(-0.5f * (u * u + v * v));   // op * G, un-clamped
+                                int cg = __float_as_int(rdl(lv.w, l0 + 2));
 #pragma unroll
                                 for (int i = 0; i < LRT_CHUNK; i++) {                 // sorted insert, forward.cu:336-352
                                     const bool sw = kt[i] > ct;
