@@ -60,6 +60,9 @@ struct lrt_state {
     int n_nodes, n_leaves;
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
+    // composited-hit record (forward with training=1 -> replay backward)
+    float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
+    size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -197,7 +200,118 @@ struct TraceParams {
     unsigned* tile_counter;
     unsigned long long* stats;
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
+    // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [j*HW + r]
+    float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
 };
+
+
+struct RayAcc { float T, C0, C1, C2, Dd, Wt, N0, N1, N2; };
+
+// colour from SH (forward.cu:67-111): + 0.5, ONLY channel 0 clamped at 0
+__device__ __forceinline__ void sh_colour(const TraceParams& p, int g, const float* b, int nsh, float& c0, float& c1, float& c2, bool& cl0)
+{
+    const float* sh = p.shs + (size_t)g * p.M * 3;
+    c0 = 0.f; c1 = 0.f; c2 = 0.f;
+    if (nsh == 16 && p.M == 16) {
+        float v[48];
+        const float4* s4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const float4 q4 = s4[j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { c0 += b[k] * v[3 * k]; c1 += b[k] * v[3 * k + 1]; c2 += b[k] * v[3 * k + 2]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nsh) { c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2]; }
+    }
+    c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+    cl0 = c0 < 0.f;
+    c0 = fmaxf(c0, 0.f);
+}
+
+// backward.cu:538-676 for ONE composited hit: running sums, dL/dalpha (incl. D1, D3), analytic gradients, atomics.
+// HAVE_AO: alpha comes from the traversal buffer (ao = op*G un-clamped); otherwise it is recomputed from the raw
+// parameters (replay of the forward's hit record).  Returns the alpha used.
+template <bool HAVE_AO>
+__device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, const float* d, const float* b, int nsh,
+                                         const float* dL, const float* fin, float dL_dbg, float t, int g, float ao_in,
+                                         RayAcc& a)
+{
+    const float mu[3] = {p.means[3 * g], p.means[3 * g + 1], p.means[3 * g + 2]};
+    const float sc[2] = {p.scales[2 * g], p.scales[2 * g + 1]};
+    const float q[4] = {p.rots[4 * g], p.rots[4 * g + 1], p.rots[4 * g + 2], p.rots[4 * g + 3]};
+    const float op = p.opac[g];
+    LrtHitGeom hg;
+    lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+    const float ao = HAVE_AO ? ao_in : op * hg.G;
+    const float alpha = fminf(LRT_ALPHA_MAX, ao);
+    const float wgt = alpha * a.T;
+    float c0, c1, c2; bool cl0;
+    sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
+    const float n0 = hg.R[2], n1 = hg.R[5], n2 = hg.R[8];
+    a.C0 += wgt * c0; a.C1 += wgt * c1; a.C2 += wgt * c2;
+    a.N0 += wgt * n0; a.N1 += wgt * n1; a.N2 += wgt * n2;
+    a.Dd += wgt * t;
+    const float T = a.T;
+    const float i1a = 1.0f / (1.0f - alpha);
+    float dLa = dL[0] * (T * c0 - (fin[0] - a.C0) * i1a) + dL[1] * (T * c1 - (fin[1] - a.C1) * i1a) +
+                dL[2] * (T * c2 - (fin[2] - a.C2) * i1a);
+    dLa += dL_dbg * (-fin[8] * i1a);                        // D1 (backward.cu:595-598)
+    dLa += dL[3] * (T * t - (fin[3] - a.Dd) * i1a);
+    dLa += dL[5] * (T * n0 - (fin[5] - a.N0) * i1a) + dL[6] * (T * n1 - (fin[6] - a.N1) * i1a) +
+           dL[7] * (T * n2 - (fin[7] - a.N2) * i1a);        // D3
+    dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
+    const float dL_dG = op * dLa;
+    unsafeAtomicAdd(p.d_opac + g, hg.G * dLa);
+    const float dNgs[3] = {dL[5] * wgt, dL[6] * wgt, dL[7] * wgt};
+    LrtHitGrad gr;
+    lrt_hit_backward(&hg, o, d, mu, sc, q, op, dL_dG, dL[3] * wgt, dNgs, &gr);
+    unsafeAtomicAdd(p.d_scales + 2 * g, gr.d_scale[0]);
+    unsafeAtomicAdd(p.d_scales + 2 * g + 1, gr.d_scale[1]);
+    for (int i2 = 0; i2 < 4; i2++) unsafeAtomicAdd(p.d_rots + 4 * g + i2, gr.d_rot[i2]);
+    for (int i2 = 0; i2 < 3; i2++) unsafeAtomicAdd(p.d_means + 3 * g + i2, gr.d_mean[i2]);
+    const float r0 = cl0 ? 0.f : dL[0] * wgt, r1 = dL[1] * wgt, r2 = dL[2] * wgt;
+    float* dsh = p.d_shs + (size_t)g * p.M * 3;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < nsh) {
+            unsafeAtomicAdd(dsh + 3 * k, b[k] * r0);
+            unsafeAtomicAdd(dsh + 3 * k + 1, b[k] * r1);
+            unsafeAtomicAdd(dsh + 3 * k + 2, b[k] * r2);
+        }
+    a.T = T * (1.f - alpha);
+    return alpha;
+}
+
+// Backward by REPLAY of the hit record the forward wrote (no traversal; the reference re-traces, backward.cu:513).
+// One lane per ray, same 64-ray tiles as the forward so that neighbouring lanes scatter into neighbouring Gaussians.
+__global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= p.n_tiles) return;
+    const int TWm = (1 << p.tw_log2) - 1, TH = 64 >> p.tw_log2;
+    const int ty = tile % p.tiles_y, tx = tile / p.tiles_y;
+    const int h = ty * TH + (lane >> p.tw_log2), w = (tx << p.tw_log2) + (lane & TWm);
+    const bool valid = (h < p.H) && (w < p.W);
+    const size_t r = valid ? ((size_t)h * p.W + w) : 0;
+    float o[3], d[3];
+    for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * r + i]; d[i] = p.ray_d[3 * r + i]; }
+    float b[16];
+    lrt_sh_basis(p.deg, d, b);
+    float dL[LRT_NCH], fin[LRT_NCH];
+    for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * r + i]; fin[i] = p.out9_in[LRT_NCH * r + i]; }
+    const float dL_dbg = dL[0] * p.bg[0] + dL[1] * p.bg[1] + dL[2] * p.bg[2];
+    RayAcc a = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = valid ? min(p.hit_n[r], p.hit_cap) : 0;
+    for (int j = 0; __any(j < n); ++j) {
+        if (j < n) {
+            const float t = p.hit_t[(size_t)j * p.hw + r];
+            const int g = p.hit_g[(size_t)j * p.hw + r];
+            bwd_hit<false>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a);
+        }
+    }
+}
 
 #define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
 
@@ -250,7 +364,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
         }
         float base = __uint_as_float(__float_as_uint(LRT_T_NEAR) - 1u);   // accept t >= 0.2 (forward.cu:214)
         bool done = !valid;
-        int dbg_n = 0;
+        int dbg_n = 0, n_rec = 0;
 
         for (int pass = 0; pass < 4096; ++pass) {   // hard bound (65k hits per ray) so a bug can never hang the GPU
             const bool act = !done;
@@ -380,66 +494,20 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                         } else {
                             const float wgt = alpha * T;
                             st_comp++;
-                            // ---- colour from SH (forward.cu:67-111), channel 0 clamped only
-                            const float* sh = p.shs + (size_t)g * p.M * 3;
-                            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-                            if (nsh == 16 && p.M == 16) {
-                                float v[48];
-                                const float4* s4 = reinterpret_cast<const float4*>(sh);
-#pragma unroll
-                                for (int j = 0; j < 12; j++) { const float4 q4 = s4[j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
-#pragma unroll
-                                for (int k = 0; k < 16; k++) { c0 += b[k] * v[3 * k]; c1 += b[k] * v[3 * k + 1]; c2 += b[k] * v[3 * k + 2]; }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 16; k++)
-                                    if (k < nsh) { c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2]; }
-                            }
-                            c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
-                            const bool cl0 = c0 < 0.f;
-                            c0 = fmaxf(c0, 0.f);
                             if (!BWD) {
+                                float c0, c1, c2; bool cl0;
+                                sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
                                 C0 += wgt * c0; C1 += wgt * c1; C2 += wgt * c2;
                                 Dd += wgt * t; Wt += wgt;
                                 unsafeAtomicAdd(p.accum + g, wgt);                      // forward.cu:268
+                                if (p.hit_t) {                                          // record for the replay backward
+                                    if (n_rec < p.hit_cap) { p.hit_t[(size_t)n_rec * p.hw + r] = t; p.hit_g[(size_t)n_rec * p.hw + r] = g; }
+                                    n_rec++;
+                                }
                             } else {
-                                // ---- backward.cu:538-676 for this hit
-                                const float mu[3] = {p.means[3 * g], p.means[3 * g + 1], p.means[3 * g + 2]};
-                                const float sc[2] = {p.scales[2 * g], p.scales[2 * g + 1]};
-                                const float q[4] = {p.rots[4 * g], p.rots[4 * g + 1], p.rots[4 * g + 2], p.rots[4 * g + 3]};
-                                const float op = p.opac[g];
-                                LrtHitGeom hg;
-                                lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-                                const float n0 = hg.R[2], n1 = hg.R[5], n2 = hg.R[8];
-                                C0 += wgt * c0; C1 += wgt * c1; C2 += wgt * c2;
-                                N0 += wgt * n0; N1 += wgt * n1; N2 += wgt * n2;
-                                Dd += wgt * t;
-                                const float i1a = 1.0f / (1.0f - alpha);
-                                float dLa = dL[0] * (T * c0 - (fin[0] - C0) * i1a) + dL[1] * (T * c1 - (fin[1] - C1) * i1a) +
-                                            dL[2] * (T * c2 - (fin[2] - C2) * i1a);
-                                dLa += dL_dbg * (-fin[8] * i1a);                        // D1 (backward.cu:595-598)
-                                dLa += dL[3] * (T * t - (fin[3] - Dd) * i1a);
-                                dLa += dL[5] * (T * n0 - (fin[5] - N0) * i1a) + dL[6] * (T * n1 - (fin[6] - N1) * i1a) +
-                                       dL[7] * (T * n2 - (fin[7] - N2) * i1a);          // D3
-                                dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
-                                const float dL_dG = op * dLa;
-                                unsafeAtomicAdd(p.d_opac + g, hg.G * dLa);
-                                const float dNgs[3] = {dL[5] * wgt, dL[6] * wgt, dL[7] * wgt};
-                                LrtHitGrad gr;
-                                lrt_hit_backward(&hg, o, d, mu, sc, q, op, dL_dG, dL[3] * wgt, dNgs, &gr);
-                                unsafeAtomicAdd(p.d_scales + 2 * g, gr.d_scale[0]);
-                                unsafeAtomicAdd(p.d_scales + 2 * g + 1, gr.d_scale[1]);
-                                for (int i2 = 0; i2 < 4; i2++) unsafeAtomicAdd(p.d_rots + 4 * g + i2, gr.d_rot[i2]);
-                                for (int i2 = 0; i2 < 3; i2++) unsafeAtomicAdd(p.d_means + 3 * g + i2, gr.d_mean[i2]);
-                                const float r0 = cl0 ? 0.f : dL[0] * wgt, r1 = dL[1] * wgt, r2 = dL[2] * wgt;
-                                float* dsh = p.d_shs + (size_t)g * p.M * 3;
-#pragma unroll
-                                for (int k = 0; k < 16; k++)
-                                    if (k < nsh) {
-                                        unsafeAtomicAdd(dsh + 3 * k, b[k] * r0);
-                                        unsafeAtomicAdd(dsh + 3 * k + 1, b[k] * r1);
-                                        unsafeAtomicAdd(dsh + 3 * k + 2, b[k] * r2);
-                                    }
+                                RayAcc a = {T, C0, C1, C2, Dd, Wt, N0, N1, N2};
+                                bwd_hit<true>(p, o, d, b, nsh, dL, fin, dL_dbg, t, g, ao, a);
+                                C0 = a.C0; C1 = a.C1; C2 = a.C2; Dd = a.Dd; N0 = a.N0; N1 = a.N1; N2 = a.N2;
                             }
                             T = testT;
                         }
@@ -453,6 +521,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
         }
 
         if (p.stats) { const unsigned long long dc = wall_clock64() - clk0; st_clk_sum += dc; st_clk_max = dc > st_clk_max ? dc : st_clk_max; }
+        if (!BWD && valid && p.hit_t) { p.hit_n[r] = n_rec; if (n_rec > p.hit_cap) atomicOr(p.hit_ovf, 1); }
         if (!BWD && valid) {
             float* op_ = p.out9 + LRT_NCH * r;
             op_[0] = C0 + T * bg0; op_[1] = C1 + T * bg1; op_[2] = C2 + T * bg2;
@@ -561,6 +630,14 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
+    st->hit_cap = 256; st->replay_enabled = 1;
+    if (hipHostMalloc((void**)&st->hit_ovf_host, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
+        delete st->timers; delete st;
+        return nullptr;
+    }
+    *st->hit_ovf_host = 0;
     if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
@@ -578,6 +655,8 @@ void lrt_destroy(lrt_state* st)
     void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->bounds, st->tile_counter, st->stats};
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
+    (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
 }
@@ -593,6 +672,11 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         return LRT_OK;
     }
     if (!strcmp(name, "no_cull")) { st->no_cull = value; return LRT_OK; }   // debug bits: 1 = no box culling, 2 = no child ordering
+    if (!strcmp(name, "hit_cap")) {            // composited hits recorded per ray for the replay backward
+        if (value < 1 || value > 65536) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: hit_cap out of range");
+        st->hit_cap = value; st->hits_valid = 0; return LRT_OK;
+    }
+    if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
         DeviceGuard dg(st->device);
         if (st->dbg) { (void)hipFree(st->dbg); st->dbg = nullptr; st->dbg_floats = 0; }
@@ -758,7 +842,31 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
-    return launch_trace(st, tp, false, stream);
+    st->hits_valid = 0;
+    const size_t HW = (size_t)H * W;
+    const bool record = training && st->replay_enabled && HW > 0 && P > 0;
+    if (record) {
+        if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
+            HIPCHK(hipStreamSynchronize(stream));
+            (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
+            st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
+            HIPCHK(hipMalloc(&st->hit_t, HW * (size_t)st->hit_cap * sizeof(float)));
+            HIPCHK(hipMalloc(&st->hit_g, HW * (size_t)st->hit_cap * sizeof(int)));
+            HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
+            st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap;
+        }
+        HIPCHK(hipMemsetAsync(st->hit_ovf, 0, sizeof(int), stream));
+        tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
+        tp.hit_cap = st->hit_cap; tp.hw = (int)HW;
+    }
+    rc = launch_trace(st, tp, false, stream);
+    if (rc) return rc;
+    if (record) {
+        HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->hit_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipEventRecord(st->hit_ev, stream));
+        st->hits_valid = 1; st->hit_H = H; st->hit_W = W;
+    }
+    return LRT_OK;
 }
 
 int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
@@ -787,7 +895,23 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.means = means; tp.scales = scales; tp.rots = rots; tp.opac = opac; tp.mod = st->mod;
     tp.out9_in = out9; tp.dL_dout = dL_dout9;
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
-    return launch_trace(st, tp, true, stream);
+    if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
+        HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
+        if (*st->hit_ovf_host == 0) {
+            const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
+            tp.tw_log2 = st->tile_w_log2; tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH;
+            tp.n_tiles = tp.tiles_x * tp.tiles_y; tp.nsh = (deg + 1) * (deg + 1);
+            tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
+            tp.hw = H * W;
+            if (tp.n_tiles > 0) {
+                ScopedTimer tm(st, 2, stream);
+                hipLaunchKernelGGL(k_bwd_replay, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+            }
+            HIPCHK(hipGetLastError());
+            return LRT_OK;
+        }
+    }
+    return launch_trace(st, tp, true, stream);   // no (complete) record: re-trace like the reference
 }
 
 }  // extern "C"
