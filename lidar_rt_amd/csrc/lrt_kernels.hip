@@ -63,6 +63,8 @@ struct lrt_state {
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
+    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float *hit_da, *hit_w;
+    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -202,10 +204,25 @@ struct TraceParams {
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [j*HW + r]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
+    // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
+    unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap;
+    float* hit_da; float* hit_w; const unsigned long long* sorted_keys; unsigned n_hits;
 };
 
 
 struct RayAcc { float T, C0, C1, C2, Dd, Wt, N0, N1, N2; };
+
+// One slot per ACTIVE lane with a single atomic per wave (callable from divergent code).
+__device__ __forceinline__ unsigned wave_alloc(unsigned* counter)
+{
+    const unsigned long long m = __ballot(1);
+    const int leader = __ffsll((long long)m) - 1;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, leader);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
 
 // colour from SH (forward.cu:67-111): + 0.5, ONLY channel 0 clamped at 0
 __device__ __forceinline__ void sh_colour(const TraceParams& p, int g, const float* b, int nsh, float& c0, float& c1, float& c2, bool& cl0)
@@ -232,10 +249,10 @@ __device__ __forceinline__ void sh_colour(const TraceParams& p, int g, const flo
 // backward.cu:538-676 for ONE composited hit: running sums, dL/dalpha (incl. D1, D3), analytic gradients, atomics.
 // HAVE_AO: alpha comes from the traversal buffer (ao = op*G un-clamped); otherwise it is recomputed from the raw
 // parameters (replay of the forward's hit record).  Returns the alpha used.
-template <bool HAVE_AO>
+template <bool HAVE_AO, bool SCATTER>
 __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, const float* d, const float* b, int nsh,
                                          const float* dL, const float* fin, float dL_dbg, float t, int g, float ao_in,
-                                         RayAcc& a)
+                                         RayAcc& a, size_t id = 0)
 {
     const float mu[3] = {p.means[3 * g], p.means[3 * g + 1], p.means[3 * g + 2]};
     const float sc[2] = {p.scales[2 * g], p.scales[2 * g + 1]};
@@ -261,6 +278,12 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
     dLa += dL[5] * (T * n0 - (fin[5] - a.N0) * i1a) + dL[6] * (T * n1 - (fin[6] - a.N1) * i1a) +
            dL[7] * (T * n2 - (fin[7] - a.N2) * i1a);        // D3
     dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
+    if (!SCATTER) {                                          // sorted-reduction backward: keep the two per-hit scalars
+        p.hit_da[id] = dLa;
+        p.hit_w[id] = cl0 ? -wgt : wgt;                      // sign bit carries the channel-0 clamp flag
+        a.T = T * (1.f - alpha);
+        return alpha;
+    }
     const float dL_dG = op * dLa;
     unsafeAtomicAdd(p.d_opac + g, hg.G * dLa);
     const float dNgs[3] = {dL[5] * wgt, dL[6] * wgt, dL[7] * wgt};
@@ -285,6 +308,7 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
 
 // Backward by REPLAY of the hit record the forward wrote (no traversal; the reference re-traces, backward.cu:513).
 // One lane per ray, same 64-ray tiles as the forward so that neighbouring lanes scatter into neighbouring Gaussians.
+template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
 {
     const int lane = threadIdx.x & 63;
@@ -308,8 +332,84 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
         if (j < n) {
             const float t = p.hit_t[(size_t)j * p.hw + r];
             const int g = p.hit_g[(size_t)j * p.hw + r];
-            bwd_hit<false>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a);
+            bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, (size_t)j * p.hw + r);
         }
+    }
+}
+
+// Sorted segmented reduction of the per-hit gradients (deterministic, almost atomic-free): thread c owns CH consecutive
+// entries of the (g, id)-sorted hit list, accumulates each run of equal g in registers and writes it once; only runs
+// that continue across a chunk boundary use atomics.
+#define LRT_RED_CH 16
+__global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long i0 = (unsigned long long)c * LRT_RED_CH;
+    if (i0 >= p.n_hits) return;
+    const unsigned long long i1 = (i0 + LRT_RED_CH < p.n_hits) ? i0 + LRT_RED_CH : p.n_hits;
+    const int nsh = p.nsh;
+    float am[3], as[2], ar[4], aop, ash[48];
+    float mu[3], sc[2], q[4], op = 0.f;
+    int cur = -1; bool shared = false;
+    auto flush = [&](int g, bool sh_) {
+        float* dm = p.d_means + 3 * (size_t)g; float* ds = p.d_scales + 2 * (size_t)g; float* dr = p.d_rots + 4 * (size_t)g;
+        float* dsh = p.d_shs + (size_t)g * p.M * 3;
+        if (sh_) {
+            for (int k = 0; k < 3; k++) unsafeAtomicAdd(dm + k, am[k]);
+            for (int k = 0; k < 2; k++) unsafeAtomicAdd(ds + k, as[k]);
+            for (int k = 0; k < 4; k++) unsafeAtomicAdd(dr + k, ar[k]);
+            unsafeAtomicAdd(p.d_opac + g, aop);
+#pragma unroll
+            for (int k = 0; k < 48; k++) if (k < 3 * nsh) unsafeAtomicAdd(dsh + k, ash[k]);
+        } else {
+            for (int k = 0; k < 3; k++) dm[k] = am[k];
+            for (int k = 0; k < 2; k++) ds[k] = as[k];
+            for (int k = 0; k < 4; k++) dr[k] = ar[k];
+            p.d_opac[g] = aop;
+#pragma unroll
+            for (int k = 0; k < 48; k++) if (k < 3 * nsh) dsh[k] = ash[k];
+        }
+    };
+    for (unsigned long long i = i0; i < i1; ++i) {
+        const unsigned long long key = p.sorted_keys[i];
+        const int g = (int)(key >> 32);
+        const unsigned id = (unsigned)key;
+        if (g != cur) {
+            if (cur >= 0) flush(cur, shared);
+            cur = g;
+            shared = (i == i0) && (i0 > 0) && ((int)(p.sorted_keys[i0 - 1] >> 32) == g);
+            for (int k = 0; k < 3; k++) { mu[k] = p.means[3 * (size_t)g + k]; am[k] = 0.f; }
+            for (int k = 0; k < 2; k++) { sc[k] = p.scales[2 * (size_t)g + k]; as[k] = 0.f; }
+            for (int k = 0; k < 4; k++) { q[k] = p.rots[4 * (size_t)g + k]; ar[k] = 0.f; }
+            op = p.opac[g]; aop = 0.f;
+#pragma unroll
+            for (int k = 0; k < 48; k++) ash[k] = 0.f;
+        }
+        const unsigned r = id % (unsigned)p.hw;
+        const float t = p.hit_t[id], da = p.hit_da[id], ws = p.hit_w[id];
+        const float w = fabsf(ws);
+        float o[3], d[3];
+        for (int k = 0; k < 3; k++) { o[k] = p.ray_o[3 * (size_t)r + k]; d[k] = p.ray_d[3 * (size_t)r + k]; }
+        const float* dL = p.dL_dout + LRT_NCH * (size_t)r;
+        LrtHitGeom hg;
+        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+        aop += hg.G * da;
+        const float dNgs[3] = {dL[5] * w, dL[6] * w, dL[7] * w};
+        LrtHitGrad gr;
+        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, dL[3] * w, dNgs, &gr);
+        for (int k = 0; k < 3; k++) am[k] += gr.d_mean[k];
+        for (int k = 0; k < 2; k++) as[k] += gr.d_scale[k];
+        for (int k = 0; k < 4; k++) ar[k] += gr.d_rot[k];
+        float b[16];
+        lrt_sh_basis(p.deg, d, b);
+        const float r0 = (ws < 0.f) ? 0.f : dL[0] * w, r1 = dL[1] * w, r2 = dL[2] * w;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nsh) { ash[3 * k] += b[k] * r0; ash[3 * k + 1] += b[k] * r1; ash[3 * k + 2] += b[k] * r2; }
+    }
+    if (cur >= 0) {
+        const bool cont = (i1 < p.n_hits) && ((int)(p.sorted_keys[i1] >> 32) == cur);
+        flush(cur, shared || cont);
     }
 }
 
@@ -501,12 +601,19 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                                 Dd += wgt * t; Wt += wgt;
                                 unsafeAtomicAdd(p.accum + g, wgt);                      // forward.cu:268
                                 if (p.hit_t) {                                          // record for the replay backward
-                                    if (n_rec < p.hit_cap) { p.hit_t[(size_t)n_rec * p.hw + r] = t; p.hit_g[(size_t)n_rec * p.hw + r] = g; }
+                                    if (n_rec < p.hit_cap) {
+                                        const size_t id = (size_t)n_rec * p.hw + r;
+                                        p.hit_t[id] = t; p.hit_g[id] = g;
+                                        if (p.hit_keys) {
+                                            const unsigned slot = wave_alloc(p.hit_count);
+                                            if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
+                                        }
+                                    }
                                     n_rec++;
                                 }
                             } else {
                                 RayAcc a = {T, C0, C1, C2, Dd, Wt, N0, N1, N2};
-                                bwd_hit<true>(p, o, d, b, nsh, dL, fin, dL_dbg, t, g, ao, a);
+                                bwd_hit<true, true>(p, o, d, b, nsh, dL, fin, dL_dbg, t, g, ao, a);
                                 C0 = a.C0; C1 = a.C1; C2 = a.C2; Dd = a.Dd; N0 = a.N0; N1 = a.N1; N2 = a.N2;
                             }
                             T = testT;
@@ -630,14 +737,14 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1;
-    if (hipHostMalloc((void**)&st->hit_ovf_host, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess) {
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2;
+    if (hipHostMalloc((void**)&st->hit_ovf_host, 2 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
         delete st->timers; delete st;
         return nullptr;
     }
-    *st->hit_ovf_host = 0;
+    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0;
     if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
@@ -656,6 +763,8 @@ void lrt_destroy(lrt_state* st)
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
+    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_da);
+    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -677,6 +786,10 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->hit_cap = value; st->hits_valid = 0; return LRT_OK;
     }
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
+    if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
+        if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
+        st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
+    }
     if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
         DeviceGuard dg(st->device);
         if (st->dbg) { (void)hipFree(st->dbg); st->dbg = nullptr; st->dbg_floats = 0; }
@@ -848,21 +961,38 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
-            (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
+            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_da, st->hit_w, st->bsort_tmp};
+            for (void* q : olds) (void)hipFree(q);
             st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
-            HIPCHK(hipMalloc(&st->hit_t, HW * (size_t)st->hit_cap * sizeof(float)));
-            HIPCHK(hipMalloc(&st->hit_g, HW * (size_t)st->hit_cap * sizeof(int)));
+            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_da = st->hit_w = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0;
+            const size_t nrec = HW * (size_t)st->hit_cap;
+            if (nrec >= (1ull << 32)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: H*W*hit_cap exceeds 2^32 (lower the hit_cap option)");
+            HIPCHK(hipMalloc(&st->hit_t, nrec * sizeof(float)));
+            HIPCHK(hipMalloc(&st->hit_g, nrec * sizeof(int)));
+            HIPCHK(hipMalloc(&st->hit_da, nrec * sizeof(float)));
+            HIPCHK(hipMalloc(&st->hit_w, nrec * sizeof(float)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
+            const size_t kc = HW * (size_t)(st->hit_cap < 64 ? st->hit_cap : 64);     // dense key list: 64 hits/ray on average
+            HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc(&st->hit_keys_sorted, kc * sizeof(unsigned long long)));
+            size_t tmpb = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpb, st->hit_keys, st->hit_keys_sorted, kc, 0, 64, stream));
+            st->bsort_tmp_bytes = tmpb + 256;
+            HIPCHK(hipMalloc(&st->bsort_tmp, st->bsort_tmp_bytes));
+            st->key_cap = (unsigned)(kc < 0xffffffffull ? kc : 0xffffffffull);
             st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap;
         }
         HIPCHK(hipMemsetAsync(st->hit_ovf, 0, sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(st->hit_count, 0, sizeof(unsigned), stream));
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW;
+        if (st->bwd_mode == 2) { tp.hit_keys = st->hit_keys; tp.hit_count = st->hit_count; tp.key_cap = st->key_cap; }
     }
     rc = launch_trace(st, tp, false, stream);
     if (rc) return rc;
     if (record) {
         HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->hit_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 1, st->hit_count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipEventRecord(st->hit_ev, stream));
         st->hits_valid = 1; st->hit_H = H; st->hit_W = W;
     }
@@ -897,15 +1027,30 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (*st->hit_ovf_host == 0) {
+        const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
+        if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
             tp.tw_log2 = st->tile_w_log2; tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH;
             tp.n_tiles = tp.tiles_x * tp.tiles_y; tp.nsh = (deg + 1) * (deg + 1);
             tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
             tp.hw = H * W;
-            if (tp.n_tiles > 0) {
+            const bool sorted = (st->bwd_mode == 2) && st->hit_keys && n_hits <= st->key_cap;
+            if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
-                hipLaunchKernelGGL(k_bwd_replay, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+                hipLaunchKernelGGL(k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+            } else if (tp.n_tiles > 0) {
+                // (1) per-ray replay -> two scalars per hit, (2) radix sort of the (g, id) keys, (3) segmented reduction
+                ScopedTimer tm(st, 2, stream);
+                tp.hit_da = st->hit_da; tp.hit_w = st->hit_w;
+                hipLaunchKernelGGL(k_bwd_replay<false>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+                if (n_hits > 0) {
+                    int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
+                    size_t tmpb = st->bsort_tmp_bytes;
+                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, 0, 32 + gbits, stream));
+                    tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
+                    const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
+                    hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
+                }
             }
             HIPCHK(hipGetLastError());
             return LRT_OK;

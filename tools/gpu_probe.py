@@ -105,6 +105,7 @@ def main():
     report = {"device": torch.cuda.get_device_name(0)}
     print(report, flush=True)
     tr = Tracer()
+    tr.optix_context.set_option("bwd_mode", int(os.environ.get("LRT_BWD_MODE", "2")))
     bg = scenes.BG_DEFAULT
     # tiny
     sc = {k: v.copy() for k, v in scenes.make_scene(64, seed=3, radius_scale=0.2).items()}
