@@ -51,7 +51,7 @@ struct lrt_state {
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
-    float* nodes; size_t cap_nodes;
+    float* nodes; float* nodes_aos; size_t cap_nodes;
     unsigned* bounds;    // 6 ordered-uint (min xyz, max xyz)
     unsigned* tile_counter;
     unsigned long long* stats;   // 8 counters
@@ -64,7 +64,9 @@ struct lrt_state {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float *hit_da, *hit_w;
-    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;
+    int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
+    int tile16_w_log2; float slab0; int* err_flag;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -148,7 +150,8 @@ __global__ void k_make_records(int P, const uint32_t* __restrict__ order, const 
 }
 
 // Level-1 nodes: child c of node j is leaf 8j+c = sorted primitives [LEAF*(8j+c), +LEAF).
-__global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __restrict__ aabb, float* __restrict__ nodes)
+__global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __restrict__ aabb, float* __restrict__ nodes,
+                         float* __restrict__ nodes_aos)
 {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     int j = tid >> 3, c = tid & 7;
@@ -163,10 +166,15 @@ __global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __res
     const bool empty = lo[0] > hi[0];
     for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(j * 8); nd[49] = __int_as_float(1); }   // children = leaves, base leaf 8j
+    float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
+    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], lo[1], lo[2], hi[0]);
+    na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
+                  : make_float4(hi[1], hi[2], __int_as_float(leaf), __int_as_float(1));       // flags: 1 = leaf, 2 = empty
 }
 
 // Level-l nodes (l >= 2): child c of node j is node 8j+c of level l-1.
-__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* __restrict__ nodes)
+__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* __restrict__ nodes,
+                        float* __restrict__ nodes_aos)
 {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     int j = tid >> 3, c = tid & 7;
@@ -184,6 +192,10 @@ __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, f
     const bool empty = lo[0] > hi[0];
     for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(child_off + j * 8); nd[49] = __int_as_float(0); }
+    float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
+    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], lo[1], lo[2], hi[0]);
+    na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
+                  : make_float4(hi[1], hi[2], __int_as_float(child_off + ch), __int_as_float(0));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -207,6 +219,8 @@ struct TraceParams {
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap;
     float* hit_da; float* hit_w; const unsigned long long* sorted_keys; unsigned n_hits;
+    // collect & resolve forward
+    float slab0; int* err_flag;
 };
 
 
@@ -646,6 +660,8 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
     }
 }
 
+#include "lrt_collect.inc"
+
 __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -680,8 +696,9 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos};
     for (void* q : olds) (void)hipFree(q);
+    st->nodes_aos = nullptr;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
@@ -698,6 +715,7 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     int total = tree_layout((int)cap, &nl, &L, cnt, off);
     st->cap_nodes = (size_t)total + 16;
     HIPCHK(hipMalloc(&st->nodes, st->cap_nodes * LRT_NODE_FLOATS * sizeof(float)));
+    HIPCHK(hipMalloc(&st->nodes_aos, st->cap_nodes * LRT_NODE_FLOATS * sizeof(float)));
     st->capP = cap;
     return LRT_OK;
 }
@@ -737,14 +755,15 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2;
-    if (hipHostMalloc((void**)&st->hit_ovf_host, 2 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 8.0f;
+    if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
         delete st->timers; delete st;
         return nullptr;
     }
-    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0;
+    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0; st->hit_ovf_host[2] = 0;
     if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
@@ -759,12 +778,12 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->bounds, st->tile_counter, st->stats};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->tile_counter, st->stats};
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_da);
-    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp);
+    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -786,6 +805,14 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->hit_cap = value; st->hits_valid = 0; return LRT_OK;
     }
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
+    if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 or 1"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
+        int l2 = -1;
+        for (int i = 0; i <= 4; i++) if ((1 << i) == value) l2 = i;
+        if (l2 < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: tile16_w must be 1, 2, 4, 8 or 16");
+        st->tile16_w_log2 = l2; return LRT_OK;
+    }
+    if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
         if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
@@ -895,9 +922,9 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
     int total = tree_layout(P, &nl, &L, cnt, off);
     if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
-    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes);
+    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
     for (int l = 2; l <= L; l++)
-        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes);
+        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
     st->P = P; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
     return LRT_OK;
@@ -988,8 +1015,24 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW;
         if (st->bwd_mode == 2) { tp.hit_keys = st->hit_keys; tp.hit_count = st->hit_count; tp.key_cap = st->key_cap; }
     }
-    rc = launch_trace(st, tp, false, stream);
-    if (rc) return rc;
+    if (st->fwd_mode == 1) {
+        const int TW = 1 << st->tile16_w_log2, TH = CR_RAYS / TW;
+        tp.tw_log2 = st->tile16_w_log2;
+        tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
+        tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
+        tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag;
+        if (tp.n_tiles > 0) {
+            HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
+            int blocks = tp.n_tiles < 256 * 16 ? tp.n_tiles : 256 * 16;          // persistent single-wave workgroups
+            ScopedTimer tm(st, 1, stream);
+            hipLaunchKernelGGL(k_fwd_cr, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+        }
+        HIPCHK(hipGetLastError());
+    } else {
+        rc = launch_trace(st, tp, false, stream);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 2, st->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     if (record) {
         HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->hit_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 1, st->hit_count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1027,6 +1070,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
+        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow (more than 64 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0");
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
         if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
