@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "liblrt_hip.so")
+LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
 
 EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_forward",
            "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing")

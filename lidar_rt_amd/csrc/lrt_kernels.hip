@@ -66,7 +66,7 @@ struct lrt_state {
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float *hit_da, *hit_w;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -220,7 +220,7 @@ struct TraceParams {
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap;
     float* hit_da; float* hit_w; const unsigned long long* sorted_keys; unsigned n_hits;
     // collect & resolve forward
-    float slab0; int* err_flag;
+    float slab0; int* err_flag; float* cr_lists;
 };
 
 
@@ -244,12 +244,14 @@ __device__ __forceinline__ void sh_colour(const TraceParams& p, int g, const flo
     const float* sh = p.shs + (size_t)g * p.M * 3;
     c0 = 0.f; c1 = 0.f; c2 = 0.f;
     if (nsh == 16 && p.M == 16) {
-        float v[48];
         const float4* s4 = reinterpret_cast<const float4*>(sh);
 #pragma unroll
-        for (int j = 0; j < 12; j++) { const float4 q4 = s4[j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { c0 += b[k] * v[3 * k]; c1 += b[k] * v[3 * k + 1]; c2 += b[k] * v[3 * k + 2]; }
+        for (int j = 0; j < 4; j++) {                       // 4 coefficients (3 float4 = 12 floats) at a time
+            const float4 x = s4[3 * j], y = s4[3 * j + 1], z = s4[3 * j + 2];
+            c0 += b[4 * j] * x.x + b[4 * j + 1] * x.w + b[4 * j + 2] * y.z + b[4 * j + 3] * z.y;
+            c1 += b[4 * j] * x.y + b[4 * j + 1] * y.x + b[4 * j + 2] * y.w + b[4 * j + 3] * z.z;
+            c2 += b[4 * j] * x.z + b[4 * j + 1] * y.y + b[4 * j + 2] * z.x + b[4 * j + 3] * z.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++)
@@ -783,7 +785,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_da);
-    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag);
+    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1021,9 +1023,18 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
         tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
         tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag;
+        tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 4) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
-            int blocks = tp.n_tiles < 256 * 16 ? tp.n_tiles : 256 * 16;          // persistent single-wave workgroups
+            int blocks = tp.n_tiles < 256 * 12 ? tp.n_tiles : 256 * 12;          // persistent single-wave workgroups
+            if (blocks > st->cr_blocks_cap) {
+                HIPCHK(hipStreamSynchronize(stream));
+                (void)hipFree(st->cr_lists); st->cr_lists = nullptr; st->cr_blocks_cap = 0;
+                const int cap = blocks < 256 ? 256 : 256 * 12;
+                HIPCHK(hipMalloc(&st->cr_lists, (size_t)cap * CR_LIST_WORDS * sizeof(float)));
+                st->cr_blocks_cap = cap;
+            }
+            tp.cr_lists = st->cr_lists;
             ScopedTimer tm(st, 1, stream);
             hipLaunchKernelGGL(k_fwd_cr, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
         }
@@ -1070,7 +1081,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow (more than 64 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0");
+        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow (more than 256 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0");
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
         if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Developer tool: per-tile clock/slab/node/prim profile of the collect&resolve forward on S1M."""
+import os, sys, ctypes as C
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+from lidar_rt_amd import scenes
+from lidar_rt_amd.parallel import HipBackend
+dev = torch.device("cuda:0")
+sc, ro, rd = scenes.s1m()
+t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
+ray_o, ray_d = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
+bg = torch.as_tensor(scenes.BG_DEFAULT, device=dev)
+be = HipBackend()
+be.state.set_option("debug_rays", 8192)   # 8192*64 floats >= 4 per tile
+be.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+for _ in range(2):
+    be.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+be.state.enable_stats(True); be.state.enable_timing(True)
+be.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+st = be.state.get_stats(dev); tm = be.state.get_timing(dev)
+idx, h = be.state.handle(dev)
+buf = np.empty((16, 512, 4), np.float32)
+be.state._lib.lrt_debug_read(h, 4, buf.ctypes.data_as(C.c_void_p), buf.nbytes, None)
+print("fwd ms", tm["fwd"], "stats", st)
+clk = buf[..., 0] / 100.0   # us
+print("tile clk us: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (clk.mean(), np.percentile(clk, 50), np.percentile(clk, 90), np.percentile(clk, 99), clk.max()))
+for name, k in (("clk_us", None), ("slabs", 1), ("nodes", 2), ("prim_rounds", 3)):
+    v = clk if k is None else buf[..., k]
+    print(name, "by tile row:", np.round(v.mean(1), 1).tolist())
+    print(name, "max by tile row:", np.round(v.max(1), 1).tolist())
