@@ -1,0 +1,89 @@
+"""Counterpart of the reference's one caller of the operator,
+``lib/gaussian_renderer/__init__.py:15-181`` ``raytracing(frame, gaussian_assets, sensor, background, args, ...)``:
+same signature, same return dict keys and channel semantics, but the
+build2DRectangle + GAS rebuild + trace chain is the fused HIP path
+(``Tracer.build_from_gaussians`` -> LBVH, ``Tracer.forward`` -> collect & resolve).
+
+The Gaussian assets / sensor are duck-typed exactly as the reference uses them:
+  asset.get_world_xyz(frame) (P,3) | asset.get_opacity (P,1) | asset.get_scaling (P,2)
+  asset.get_rotation(frame) -> (actor_quat (1,4) or (4,), local_quat (P,4)) | asset.get_features (P,M,3)
+  asset.active_sh_degree
+  sensor.get_range_rays(frame) -> (rays_o (H,W,3) [expanded view], rays_d (H,W,3)); sensor.sensor_center[frame]
+  or sensor = (rays_o, rays_d, center) tuple (reference :44-46)
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .diff_lidar_tracer import Tracer, TracingSettings
+
+tracer_2dgs = None          # module-level singleton like the reference (:11), created lazily (needs the HIP library)
+
+
+def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Hamilton product, real part first (lib/utils/general_utils.py:156-174)."""
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifier=1.0, override_color=None,
+               decomp=False):
+    global tracer_2dgs
+    if tracer_2dgs is None:
+        tracer_2dgs = Tracer()
+    if decomp == "background":
+        gaussian_assets = gaussian_assets[:1]
+    elif decomp == "object":
+        gaussian_assets = gaussian_assets[1:]
+    if isinstance(sensor, tuple):
+        rays_o, rays_d, sensor_center = sensor[0], sensor[1], sensor[2]
+    elif hasattr(sensor, "get_range_rays"):
+        rays_o, rays_d = sensor.get_range_rays(frame)
+        sensor_center = sensor.sensor_center[frame]
+    else:
+        raise ValueError("sensor type not supported")
+    if override_color is not None or getattr(getattr(args, "pipe", None), "convert_SHs_python", False) or \
+            getattr(getattr(args, "pipe", None), "compute_cov3D_python", False):
+        raise NotImplementedError("precomputed colours / covariances are not supported by the tracer kernels "
+                                  "(the reference forward ignores them too, forward.cu:261-263)")
+    dev = rays_d.device
+    e = torch.empty(0, device=dev)
+    settings = TracingSettings(None, None, None, None, background.to(dev, torch.float32), 1.0, e, e,
+                               gaussian_assets[0].active_sh_degree, sensor_center.to(dev), False, False)
+    means, opac, scales, shs, obj_rot, rot_local = [], [], [], [], [], []
+    for pc in gaussian_assets:
+        means.append(pc.get_world_xyz(frame)); opac.append(pc.get_opacity); scales.append(pc.get_scaling)
+        r1, r2 = pc.get_rotation(frame)
+        obj_rot.append(r1.expand(r2.shape[0], -1)); rot_local.append(r2)
+        shs.append(pc.get_features)
+    means3D = torch.cat(means, 0); opacity = torch.cat(opac, 0); scales = torch.cat(scales, 0); shs = torch.cat(shs, 0)
+    dynamic = bool(getattr(args, "dynamic", False))
+    if decomp == "background" or not dynamic:
+        rotations = rot_local[0]
+    elif decomp == "object":
+        rotations = quaternion_raw_multiply(torch.cat(obj_rot, 0), F.normalize(torch.cat(rot_local, 0), dim=1))
+    else:
+        rot_obj = quaternion_raw_multiply(torch.cat(obj_rot[1:], 0), F.normalize(torch.cat(rot_local[1:], 0), dim=1))
+        rotations = torch.cat([rot_local[0], rot_obj], 0)
+    grads3D = torch.zeros_like(means3D, requires_grad=True)
+    try:
+        means3D.retain_grad()          # train.py:219 reads means3D.grad
+    except Exception:
+        pass
+    # fused replacement of primitiveCallback(...) + tracer.build_acceleration_structure(vertices, faces, rebuild=True)
+    tracer_2dgs.build_from_gaussians(means3D, scales, rotations, opacity)
+    rendered, accum = tracer_2dgs(ray_o=rays_o, ray_d=rays_d, mesh_normals=None, means3D=means3D, grads3D=grads3D,
+                                  shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
+                                  rotations=rotations, cov3Ds_precomp=None, tracer_settings=settings)
+    intensities, rayhit_logits = rendered[:, :, 0:1], rendered[:, :, 1:2]
+    raydrop_logits, depth = rendered[:, :, 2:3], rendered[:, :, 3:4]
+    if getattr(getattr(args, "opt", None), "use_rayhit", False):
+        prob = F.softmax(torch.cat([rayhit_logits, raydrop_logits], dim=-1), dim=-1)
+        raydrop_prob = prob[..., 1:2]
+    else:
+        raydrop_prob = torch.sigmoid(raydrop_logits)
+    return {"depth": depth, "intensity": intensities, "raydrop": raydrop_prob, "means3D": means3D,
+            "accum_gaussian_weight": accum.unsqueeze(-1)}
