@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into the committed summaries
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_summary.md and profiles/pmc_traffic.json (read by bench.py)."""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(REPO, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
+    if len(name) > 90:
+        m = re.search(r"(radix_sort_[a-z_]+|merge_sort_[a-z_]+|onesweep[a-z_]*|block_sort[a-z_]*|histogram[a-z_]*)", name)
+        name = "rocprim::" + (m.group(1) if m else name[-60:])
+    return name.replace("void ", "")
+
+
+rows = list(csv.DictReader(open(os.path.join(src, "stats", "s_kernel_stats.csv"))))
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,total_ms,avg_us,percent,min_us,max_us\n")
+    for r in rows:
+        f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.2f},"
+                f"{r['Percentage']},{float(r['MinNs'])/1e3:.2f},{float(r['MaxNs'])/1e3:.2f}\n")
+
+pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
+    p = os.path.join(src, sub, "p_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        k = short(r["Kernel_Name"])
+        c = pmc[k][r["Counter_Name"]]
+        c[0] += float(r["Counter_Value"]); c[1] += 1
+
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+
+traffic = {}
+lines = [f"# rocprofv3 summary `{tag}` (MI355X, `python bench.py --steps 20 --warmup 3 --no-cpu-baseline`)\n",
+         "Raw rocprofv3 outputs were written under `gpurun_out/prof_%s/` on the GPU box; this file is the committed digest.\n" % tag]
+if bench:
+    lines.append(f"bench line under `--kernel-trace --stats`: **{bench['value']/1e6:.2f} M rays/s**, {bench['ms_per_step']:.3f} ms/step; "
+                 f"bench's own HIP-event averages: {bench['roofline']['avg_kernel_ms']}\n")
+lines.append("## Kernel time (`--kernel-trace --stats`)\n")
+lines.append("| kernel | calls | avg us | % of GPU time |\n|---|---:|---:|---:|")
+for r in rows[:14]:
+    lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |")
+lines.append("\n## PMC (separate `--pmc` passes; per-launch averages)\n")
+lines.append("FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half of the bytes of wide "
+             "coalesced reads, so `hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024` is used as the corrected traffic (the uncorrected sum is shown too).\n")
+lines.append("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | traffic MB (corrected) | traffic MB (raw) | L2 hit % | SQ active % | SQ wait-any % | SQ issue-stall % | VALU insts/launch |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 1])[0]):
+    if not any(s in k for s in ("k_", "radix", "sort", "onesweep")):
+        continue
+    def avg(n):
+        return c[n][0] / c[n][1] if n in c and c[n][1] else None
+    fs, ws = avg("FETCH_SIZE"), avg("WRITE_SIZE")
+    hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
+    wc = avg("SQ_WAVE_CYCLES")
+    corr = (2 * (fs or 0) + (ws or 0)) * 1024 / 1e6
+    raw = ((fs or 0) + (ws or 0)) * 1024 / 1e6
+    f = lambda v, d=1: "-" if v is None else f"{v:.{d}f}"
+    pct = lambda n: "-" if not wc or avg(n) is None else f"{100*avg(n)/wc:.0f}"
+    l2 = "-" if hit is None or miss is None or hit + miss == 0 else f"{100*hit/(hit+miss):.0f}"
+    vi = avg("SQ_INSTS_VALU")
+    lines.append(f"| `{k}` | {f(fs)} | {f(ws)} | {corr:.1f} | {raw:.1f} | {l2} | {pct('SQ_ACTIVE_INST_ANY')} | {pct('SQ_WAIT_ANY')} | {pct('SQ_WAIT_INST_ANY')} | {f(vi,0)} |")
+    if fs is not None or ws is not None:
+        traffic[k] = {"hbm_bytes_per_launch": corr * 1e6, "fetch_kb": fs, "write_kb": ws, "raw_bytes_per_launch": raw * 1e6}
+
+# labels bench.py uses for the dominant kernel
+fwd = traffic.get("k_fwd_cr")
+if fwd:
+    traffic["k_fwd_cr (collect & resolve forward)"] = fwd
+bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
+if bw:
+    traffic["backward (k_bwd_replay + radix sort + k_bwd_reduce)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
