@@ -63,7 +63,7 @@ struct lrt_state {
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
-    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float *hit_da, *hit_w;
+    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
@@ -97,8 +97,16 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
         }
     }
     for (int i = 0; i < 3; i++) { lo[i] = wave_min(lo[i]); hi[i] = wave_max(hi[i]); }
-    if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 3; i++) { atomicMin(bounds + i, f2ord(lo[i])); atomicMax(bounds + 3 + i, f2ord(hi[i])); }
+    __shared__ float s_lo[4][3], s_hi[4][3];                     // 256-thread blocks: 4 waves -> one atomic set per block
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 3; i++) { s_lo[wv][i] = lo[i]; s_hi[wv][i] = hi[i]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int i = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][i], s_lo[1][i]), fminf(s_lo[2][i], s_lo[3][i]));
+        const float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
+        atomicMin(bounds + i, f2ord(l)); atomicMax(bounds + 3 + i, f2ord(h));
+    }
 }
 
 __global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
@@ -218,7 +226,9 @@ struct TraceParams {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap;
-    float* hit_da; float* hit_w; const unsigned long long* sorted_keys; unsigned n_hits;
+    const unsigned long long* sorted_keys; unsigned n_hits;
+    float4* hit_pk;        // per hit (t, dL/dalpha, +-w, -) written by k_bwd_replay<false>, one 16-B gather in k_bwd_reduce
+    float4* ray_pk;        // per ray 4 x float4: (o, dL3) (d, -) (dL0..2, -) (dL5..7, -)
     // collect & resolve forward
     float slab0; int* err_flag; float* cr_lists;
 };
@@ -295,8 +305,7 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
            dL[7] * (T * n2 - (fin[7] - a.N2) * i1a);        // D3
     dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
     if (!SCATTER) {                                          // sorted-reduction backward: keep the two per-hit scalars
-        p.hit_da[id] = dLa;
-        p.hit_w[id] = cl0 ? -wgt : wgt;                      // sign bit carries the channel-0 clamp flag
+        p.hit_pk[id] = make_float4(t, dLa, cl0 ? -wgt : wgt, 0.f);   // sign of w carries the channel-0 clamp flag
         a.T = T * (1.f - alpha);
         return alpha;
     }
@@ -343,6 +352,11 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
     for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * r + i]; fin[i] = p.out9_in[LRT_NCH * r + i]; }
     const float dL_dbg = dL[0] * p.bg[0] + dL[1] * p.bg[1] + dL[2] * p.bg[2];
     RayAcc a = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!SCATTER && valid) {
+        float4* rp = p.ray_pk + 4 * r;
+        rp[0] = make_float4(o[0], o[1], o[2], dL[3]); rp[1] = make_float4(d[0], d[1], d[2], 0.f);
+        rp[2] = make_float4(dL[0], dL[1], dL[2], 0.f); rp[3] = make_float4(dL[5], dL[6], dL[7], 0.f);
+    }
     const int n = valid ? min(p.hit_n[r], p.hit_cap) : 0;
     for (int j = 0; __any(j < n); ++j) {
         if (j < n) {
@@ -402,11 +416,12 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
             for (int k = 0; k < 48; k++) ash[k] = 0.f;
         }
         const unsigned r = id % (unsigned)p.hw;
-        const float t = p.hit_t[id], da = p.hit_da[id], ws = p.hit_w[id];
+        const float4 hp = p.hit_pk[id];
+        const float t = hp.x, da = hp.y, ws = hp.z;
         const float w = fabsf(ws);
-        float o[3], d[3];
-        for (int k = 0; k < 3; k++) { o[k] = p.ray_o[3 * (size_t)r + k]; d[k] = p.ray_d[3 * (size_t)r + k]; }
-        const float* dL = p.dL_dout + LRT_NCH * (size_t)r;
+        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
+        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
+        const float dL[LRT_NCH] = {r2_.x, r2_.y, r2_.z, r0_.w, 0.f, r3_.x, r3_.y, r3_.z, 0.f};
         LrtHitGeom hg;
         lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
         aop += hg.G * da;
@@ -784,8 +799,8 @@ void lrt_destroy(lrt_state* st)
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
-    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_da);
-    (void)hipFree(st->hit_w); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_pk);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -913,7 +928,7 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     if (P > 0) {
         HIPCHK(hipMemsetAsync(st->bounds, 0xff, 3 * sizeof(unsigned), stream));
         HIPCHK(hipMemsetAsync(st->bounds + 3, 0x00, 3 * sizeof(unsigned), stream));
-        int gb = (P + TB - 1) / TB; if (gb > 2048) gb = 2048;
+        int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
         hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, st->bounds);
         hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, st->bounds, st->keys_a, st->vals_a);
         size_t tmp = st->sort_tmp_bytes;
@@ -990,16 +1005,16 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
-            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_da, st->hit_w, st->bsort_tmp};
+            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp};
             for (void* q : olds) (void)hipFree(q);
             st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
-            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_da = st->hit_w = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0;
+            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0;
             const size_t nrec = HW * (size_t)st->hit_cap;
             if (nrec >= (1ull << 32)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: H*W*hit_cap exceeds 2^32 (lower the hit_cap option)");
             HIPCHK(hipMalloc(&st->hit_t, nrec * sizeof(float)));
             HIPCHK(hipMalloc(&st->hit_g, nrec * sizeof(int)));
-            HIPCHK(hipMalloc(&st->hit_da, nrec * sizeof(float)));
-            HIPCHK(hipMalloc(&st->hit_w, nrec * sizeof(float)));
+            HIPCHK(hipMalloc(&st->hit_pk, nrec * sizeof(float4)));
+            HIPCHK(hipMalloc(&st->ray_pk, HW * 4 * sizeof(float4)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
             const size_t kc = HW * (size_t)(st->hit_cap < 64 ? st->hit_cap : 64);     // dense key list: 64 hits/ray on average
             HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
@@ -1096,7 +1111,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             } else if (tp.n_tiles > 0) {
                 // (1) per-ray replay -> two scalars per hit, (2) radix sort of the (g, id) keys, (3) segmented reduction
                 ScopedTimer tm(st, 2, stream);
-                tp.hit_da = st->hit_da; tp.hit_w = st->hit_w;
+                tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk;
                 hipLaunchKernelGGL(k_bwd_replay<false>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
