@@ -63,7 +63,7 @@ struct lrt_state {
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
-    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk;
+    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
@@ -225,7 +225,7 @@ struct TraceParams {
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [j*HW + r]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
-    unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap;
+    unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off;
     const unsigned long long* sorted_keys; unsigned n_hits;
     float4* hit_pk;        // per hit (t, dL/dalpha, +-w, -) written by k_bwd_replay<false>, one 16-B gather in k_bwd_reduce
     float4* ray_pk;        // per ray 4 x float4: (o, dL3) (d, -) (dL0..2, -) (dL5..7, -)
@@ -255,9 +255,12 @@ __device__ __forceinline__ void sh_colour(const TraceParams& p, int g, const flo
     c0 = 0.f; c1 = 0.f; c2 = 0.f;
     if (nsh == 16 && p.M == 16) {
         const float4* s4 = reinterpret_cast<const float4*>(sh);
+        float4 v[12];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {                       // 4 coefficients (3 float4 = 12 floats) at a time
-            const float4 x = s4[3 * j], y = s4[3 * j + 1], z = s4[3 * j + 2];
+        for (int j = 0; j < 12; j++) v[j] = s4[j];          // all 12 loads in flight: one memory round trip per hit
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 x = v[3 * j], y = v[3 * j + 1], z = v[3 * j + 2];
             c0 += b[4 * j] * x.x + b[4 * j + 1] * x.w + b[4 * j + 2] * y.z + b[4 * j + 3] * z.y;
             c1 += b[4 * j] * x.y + b[4 * j + 1] * y.x + b[4 * j + 2] * y.w + b[4 * j + 3] * z.z;
             c2 += b[4 * j] * x.z + b[4 * j + 1] * y.y + b[4 * j + 2] * z.x + b[4 * j + 3] * z.w;
@@ -363,6 +366,10 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
             const float t = p.hit_t[(size_t)j * p.hw + r];
             const int g = p.hit_g[(size_t)j * p.hw + r];
             bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, (size_t)j * p.hw + r);
+            if (!SCATTER) {                          // dense (gidx, id) key list for the sort: slot = exclusive_scan(hit_n)[r] + j
+                const unsigned slot = p.hit_off[r] + (unsigned)j;
+                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)((size_t)j * p.hw + r);
+            }
         }
     }
 }
@@ -635,10 +642,6 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                                     if (n_rec < p.hit_cap) {
                                         const size_t id = (size_t)n_rec * p.hw + r;
                                         p.hit_t[id] = t; p.hit_g[id] = g;
-                                        if (p.hit_keys) {
-                                            const unsigned slot = wave_alloc(p.hit_count);
-                                            if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
-                                        }
                                     }
                                     n_rec++;
                                 }
@@ -659,7 +662,10 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
         }
 
         if (p.stats) { const unsigned long long dc = wall_clock64() - clk0; st_clk_sum += dc; st_clk_max = dc > st_clk_max ? dc : st_clk_max; }
-        if (!BWD && valid && p.hit_t) { p.hit_n[r] = n_rec; if (n_rec > p.hit_cap) atomicOr(p.hit_ovf, 1); }
+        if (!BWD && valid && p.hit_t) {
+            p.hit_n[r] = min(n_rec, p.hit_cap); if (n_rec > p.hit_cap) atomicOr(p.hit_ovf, 1);
+            if (p.hit_count) atomicAdd(p.hit_count, (unsigned)min(n_rec, p.hit_cap));     // no return value: fire and forget
+        }
         if (!BWD && valid) {
             float* op_ = p.out9 + LRT_NCH * r;
             op_[0] = C0 + T * bg0; op_[1] = C1 + T * bg1; op_[2] = C2 + T * bg2;
@@ -800,7 +806,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1005,10 +1011,10 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
-            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp};
+            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp};
             for (void* q : olds) (void)hipFree(q);
             st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
-            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0;
+            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0; st->hit_off = nullptr; st->scan_tmp = nullptr;
             const size_t nrec = HW * (size_t)st->hit_cap;
             if (nrec >= (1ull << 32)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: H*W*hit_cap exceeds 2^32 (lower the hit_cap option)");
             HIPCHK(hipMalloc(&st->hit_t, nrec * sizeof(float)));
@@ -1016,6 +1022,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             HIPCHK(hipMalloc(&st->hit_pk, nrec * sizeof(float4)));
             HIPCHK(hipMalloc(&st->ray_pk, HW * 4 * sizeof(float4)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
+            HIPCHK(hipMalloc(&st->hit_off, (HW + 1) * sizeof(unsigned)));
+            { size_t sb = 0; HIPCHK(rocprim::exclusive_scan(nullptr, sb, (unsigned*)st->hit_n, st->hit_off, 0u, HW, rocprim::plus<unsigned>(), stream));
+              st->scan_tmp_bytes = sb + 256; HIPCHK(hipMalloc(&st->scan_tmp, st->scan_tmp_bytes)); }
             const size_t kc = HW * (size_t)(st->hit_cap < 64 ? st->hit_cap : 64);     // dense key list: 64 hits/ray on average
             HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
             HIPCHK(hipMalloc(&st->hit_keys_sorted, kc * sizeof(unsigned long long)));
@@ -1030,7 +1039,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         HIPCHK(hipMemsetAsync(st->hit_count, 0, sizeof(unsigned), stream));
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW;
-        if (st->bwd_mode == 2) { tp.hit_keys = st->hit_keys; tp.hit_count = st->hit_count; tp.key_cap = st->key_cap; }
+        tp.hit_count = st->hit_count;
     }
     if (st->fwd_mode == 1) {
         const int TW = 1 << st->tile16_w_log2, TH = CR_RAYS / TW;
@@ -1038,7 +1047,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
         tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
         tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag;
-        tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 4) ? st->dbg : nullptr;
+        tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
             int blocks = tp.n_tiles < 256 * 12 ? tp.n_tiles : 256 * 12;          // persistent single-wave workgroups
@@ -1112,6 +1121,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 // (1) per-ray replay -> two scalars per hit, (2) radix sort of the (g, id) keys, (3) segmented reduction
                 ScopedTimer tm(st, 2, stream);
                 tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk;
+                { size_t sb = st->scan_tmp_bytes;
+                  HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
+                tp.hit_off = st->hit_off; tp.hit_keys = st->hit_keys; tp.key_cap = st->key_cap;
                 hipLaunchKernelGGL(k_bwd_replay<false>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;

@@ -19,10 +19,15 @@ be.state.enable_stats(True); be.state.enable_timing(True)
 be.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
 st = be.state.get_stats(dev); tm = be.state.get_timing(dev)
 idx, h = be.state.handle(dev)
-buf = np.empty((16, 512, 4), np.float32)
+buf = np.empty((2, 16, 512, 4), np.float32)
 be.state._lib.lrt_debug_read(h, 4, buf.ctypes.data_as(C.c_void_p), buf.nbytes, None)
 print("fwd ms", tm["fwd"], "stats", st)
+buf2 = buf[1]; buf = buf[0]
 clk = buf[..., 0] / 100.0   # us
+print("phase A us by row:", np.round(buf2[..., 0].mean(1) / 100, 0).tolist())
+print("phase B us by row:", np.round(buf2[..., 1].mean(1) / 100, 0).tolist())
+print("node batches by row:", np.round(buf2[..., 2].mean(1), 1).tolist())
+print("leaf batches by row:", np.round(buf2[..., 3].mean(1), 1).tolist())
 print("tile clk us: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (clk.mean(), np.percentile(clk, 50), np.percentile(clk, 90), np.percentile(clk, 99), clk.max()))
 for name, k in (("clk_us", None), ("slabs", 1), ("nodes", 2), ("prim_rounds", 3)):
     v = clk if k is None else buf[..., k]
