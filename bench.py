@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. fwd_mode=0, bwd_mode=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     args = ap.parse_args()
 
@@ -99,11 +100,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # developer switches to exercise the N>1 path on a 1-GPU box: all ranks on cuda:0, gloo instead of RCCL
+    single_dev = os.environ.get("LRT_SINGLE_DEVICE", "0") == "1"
+    backend = os.environ.get("LRT_DIST_BACKEND", "nccl")
+    dev_index = 0 if single_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -208,10 +216,13 @@ def main():
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
                        "step": ("LBVH rebuild + " if not args.no_build_in_step else "") + "forward + backward"
                                + (" + slab all_gather + fused gradient all_reduce (RCCL)" if world > 1 else ""),
-                       "parallelism": f"azimuth-sector x{world}", "options": args.opt},
+                       "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None},
             "roofline": roof,
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }
+        if args.check_sum:
+            res["checksums"] = {"out": float(out.double().abs().sum()), "d_means": float(g["means"].double().abs().sum()),
+                                "d_shs": float(g["shs"].double().abs().sum()), "accum": float(g["accum"].double().sum())}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(sc, ro, rd, deg, bg_np, dL_np)
