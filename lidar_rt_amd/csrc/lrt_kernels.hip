@@ -64,7 +64,7 @@ struct lrt_state {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes;
-    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode;
+    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
@@ -451,6 +451,99 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
     }
 }
 
+// Lane-per-hit variant of the segmented reduction: every lane of a wave takes ONE entry of the (g, id)-sorted hit
+// list, so the 64 gathers of a wave are independent and in flight together; the per-hit gradients are then combined
+// with a segmented inclusive scan over the wave (segments = runs of equal gidx, contiguous because sorted) and the
+// last lane of each run writes the total -- plainly if the run lies inside the wave, with atomics if it continues
+// in a neighbouring wave.
+__device__ __forceinline__ float seg_step(float v, int off, bool same, int lane)
+{
+    const float y = __shfl_up(v, off);
+    return (same && lane >= off) ? v + y : v;
+}
+
+__global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < p.n_hits;
+    const unsigned long long wave0 = i - (unsigned long long)lane;
+    const unsigned long long key = live ? p.sorted_keys[i] : ~0ull;
+    const int g = (int)(key >> 32);
+    const unsigned id = (unsigned)key;
+    const int nsh = p.nsh;
+    float acc[10], ash[48];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 48; k++) ash[k] = 0.f;
+    if (live) {
+        const unsigned r = id % (unsigned)p.hw;
+        const float4 hp = p.hit_pk[id];
+        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
+        const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
+        const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
+        const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
+        const float op = p.opac[g];
+        const float t = hp.x, da = hp.y, ws = hp.z, w = fabsf(ws);
+        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
+        LrtHitGeom hg;
+        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+        const float dNgs[3] = {r3_.x * w, r3_.y * w, r3_.z * w};
+        LrtHitGrad gr;
+        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, r0_.w * w, dNgs, &gr);
+        acc[0] = gr.d_mean[0]; acc[1] = gr.d_mean[1]; acc[2] = gr.d_mean[2];
+        acc[3] = gr.d_scale[0]; acc[4] = gr.d_scale[1];
+        acc[5] = gr.d_rot[0]; acc[6] = gr.d_rot[1]; acc[7] = gr.d_rot[2]; acc[8] = gr.d_rot[3];
+        acc[9] = hg.G * da;
+        float b[16];
+        lrt_sh_basis(p.deg, d, b);
+        const float c0 = (ws < 0.f) ? 0.f : r2_.x * w, c1 = r2_.y * w, c2 = r2_.z * w;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nsh) { ash[3 * k] = b[k] * c0; ash[3 * k + 1] = b[k] * c1; ash[3 * k + 2] = b[k] * c2; }
+    }
+    // segmented inclusive scan; same[s] = the lane 2^s below belongs to the same run
+    bool same[6];
+#pragma unroll
+    for (int s_ = 0; s_ < 6; s_++) { const int off = 1 << s_; const int gp = __shfl_up(g, off); same[s_] = (lane >= off) && (gp == g); }
+#pragma unroll
+    for (int s_ = 0; s_ < 6; s_++) {
+        const int off = 1 << s_;
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] = seg_step(acc[k], off, same[s_], lane);
+#pragma unroll
+        for (int k = 0; k < 48; k++) if (k < 3 * nsh) ash[k] = seg_step(ash[k], off, same[s_], lane);
+    }
+    const int gn = __shfl_down(g, 1);
+    const bool tail = live && (lane == 63 || gn != g);
+    // run head of this lane's run (all lanes take part in the ballot, so it precedes the early return)
+    const unsigned long long heads = __ballot(!same[0]);                 // lanes whose lower neighbour differs, and lane 0
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    const bool starts_at0 = (63 - __clzll((long long)below)) == 0;
+    if (!tail) return;
+    bool shared = false;
+    if (starts_at0 && wave0 > 0) shared = ((int)(p.sorted_keys[wave0 - 1] >> 32) == g);
+    if (lane == 63 && i + 1 < p.n_hits) shared = shared || ((int)(p.sorted_keys[i + 1] >> 32) == g);
+    float* dm = p.d_means + 3 * (size_t)g; float* ds = p.d_scales + 2 * (size_t)g; float* dr = p.d_rots + 4 * (size_t)g;
+    float* dsh = p.d_shs + (size_t)g * p.M * 3;
+    if (shared) {
+        for (int k = 0; k < 3; k++) unsafeAtomicAdd(dm + k, acc[k]);
+        for (int k = 0; k < 2; k++) unsafeAtomicAdd(ds + k, acc[3 + k]);
+        for (int k = 0; k < 4; k++) unsafeAtomicAdd(dr + k, acc[5 + k]);
+        unsafeAtomicAdd(p.d_opac + g, acc[9]);
+#pragma unroll
+        for (int k = 0; k < 48; k++) if (k < 3 * nsh) unsafeAtomicAdd(dsh + k, ash[k]);
+    } else {
+        for (int k = 0; k < 3; k++) dm[k] = acc[k];
+        for (int k = 0; k < 2; k++) ds[k] = acc[3 + k];
+        for (int k = 0; k < 4; k++) dr[k] = acc[5 + k];
+        p.d_opac[g] = acc[9];
+#pragma unroll
+        for (int k = 0; k < 48; k++) if (k < 3 * nsh) dsh[k] = ash[k];
+    }
+}
+
 #define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
 
 template <bool BWD>
@@ -778,7 +871,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 8.0f;
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 8.0f;
     if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
@@ -836,6 +929,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->tile16_w_log2 = l2; return LRT_OK;
     }
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
+    if (!strcmp(name, "reduce_mode")) { st->reduce_mode = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
         if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
@@ -1130,8 +1224,12 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     size_t tmpb = st->bsort_tmp_bytes;
                     HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, 0, 32 + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
-                    const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
-                    hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
+                    if (st->reduce_mode == 0) {
+                        const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
+                        hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
+                    } else {
+                        hipLaunchKernelGGL(k_bwd_reduce2, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
+                    }
                 }
             }
             HIPCHK(hipGetLastError());
