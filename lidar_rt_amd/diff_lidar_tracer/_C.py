@@ -204,7 +204,9 @@ def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertic
 def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, background, means3D, shs,
                            degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
                            transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
-                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32):
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None):
+    # grads_out (extension): dict of preallocated contiguous fp32 tensors 'means' (P,3), 'shs' (P,M,3), 'opacities' (P,1),
+    # 'scales' (P,2), 'rotations' (P,4) to write into (e.g. views of one flat buffer for a fused all-reduce)
     P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
               transMat_precomp)
     H, W = ray_o.size(0), ray_o.size(1)
@@ -220,14 +222,23 @@ def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, bac
     out = out_attr_float32.detach().contiguous()
     dL = dL_dout_attr_float32.detach().contiguous().to(torch.float32)
     opts = dict(dtype=torch.float32, device=dev)
-    d_means = torch.empty((P, 3), **opts); d_shs = torch.empty((P, M, 3), **opts)
-    d_opac = torch.empty((P, 1), **opts); d_scales = torch.empty((P, 2), **opts); d_rot = torch.empty((P, 4), **opts)
+    if grads_out is None:
+        d_means = torch.empty((P, 3), **opts); d_shs = torch.empty((P, M, 3), **opts)
+        d_opac = torch.empty((P, 1), **opts); d_scales = torch.empty((P, 2), **opts); d_rot = torch.empty((P, 4), **opts)
+    else:
+        d_means, d_shs, d_opac = grads_out["means"], grads_out["shs"], grads_out["opacities"]
+        d_scales, d_rot = grads_out["scales"], grads_out["rotations"]
+        for t_, shp in ((d_means, (P, 3)), (d_shs, (P, M, 3)), (d_opac, (P, 1)), (d_scales, (P, 2)), (d_rot, (P, 4))):
+            if tuple(t_.shape) != shp or not t_.is_contiguous() or t_.dtype != torch.float32 or t_.device != dev:
+                raise RuntimeError("grads_out tensors must be contiguous float32 device tensors of the gradient shapes")
     with torch.cuda.device(idx):
         _capi.check(state._lib.lrt_backward(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
                                             _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o), _capi.ptr(sh),
                                             _capi.ptr(bg), _capi.ptr(out), _capi.ptr(dL), _capi.ptr(d_means),
                                             _capi.ptr(d_shs), _capi.ptr(d_opac), _capi.ptr(d_scales),
                                             _capi.ptr(d_rot), _stream_ptr()), "lrt_backward")
+    if grads_out is not None:
+        return d_means, d_shs, None, d_opac, d_scales, d_rot, None, None
     # dead outputs of the reference (never written by backward.cu): returned as zeros
     d_colors = torch.zeros((P, 3), **opts)
     d_trans = torch.zeros((P, 9), **opts)

@@ -42,7 +42,7 @@ class GradLayout:
     def __init__(self, P: int, M: int, device, with_accum: bool = True):
         self.P, self.M = P, M
         n = P * (3 + 2 + 4 + 1 + 3 * M) + (P if with_accum else 0)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)    # every view is fully written by the backward
         self.views: Dict[str, torch.Tensor] = {}
         o = 0
         for name, k in self.FIELDS:
@@ -69,10 +69,10 @@ class HipBackend:
                                               scales, mod, rotations, e, e, e, e, False, False)
         return out, accum
 
-    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0):
+    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0, grads_out=None):
         e = torch.empty(0, device=means.device)
         g = self._C.trace_surfels_backward(self.state, ray_o, ray_d, e, bg, means, shs, deg, e, opacities, scales,
-                                           mod, rotations, e, e, e, e, False, False, out, None, dL)
+                                           mod, rotations, e, e, e, e, False, False, out, None, dL, grads_out=grads_out)
         return {"means": g[0], "shs": g[1], "opacities": g[3], "scales": g[4], "rotations": g[5]}
 
 
@@ -113,12 +113,19 @@ class ShardedTracer:
                  reduce: bool = True) -> Dict[str, torch.Tensor]:
         a, b = self._slab
         dL = dL_full[:, a:b].contiguous()
-        g = self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
-                                  self._out_loc, dL, mod)
         P = means.shape[0]; M = shs.shape[1]
-        lay = GradLayout(P, M, means.device)
-        for k in ("means", "scales", "rotations", "opacities", "shs"):
-            lay.views[k].copy_(g[k].view_as(lay.views[k]))
+        lay = getattr(self, "_layout", None)
+        if lay is None or lay.P != P or lay.M != M or lay.flat.device != means.device:
+            lay = self._layout = GradLayout(P, M, means.device)           # reused across steps: no per-step 240 MB allocation
+        direct = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
+        try:
+            self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
+                                  self._out_loc, dL, mod, grads_out=direct)      # kernels write straight into the flat buffer
+        except TypeError:                                                         # backend without grads_out (test stand-ins)
+            g = self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
+                                      self._out_loc, dL, mod)
+            for k in direct:
+                direct[k].copy_(g[k].view_as(direct[k]))
         lay.views["accum"].copy_(self._accum_loc)
         if reduce and self.world > 1:
             dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -28,6 +28,7 @@ def test_column_slabs_partition_the_image():
 def test_grad_layout_is_one_flat_buffer():
     lay = GradLayout(10, 16, "cpu")
     assert lay.flat.numel() == 10 * (3 + 2 + 4 + 1 + 48) + 10
+    lay.flat.zero_()
     lay.views["shs"].fill_(2.0); lay.views["accum"].fill_(3.0)
     assert float(lay.flat.sum()) == 10 * 48 * 2.0 + 10 * 3.0
 
