@@ -222,7 +222,7 @@ struct TraceParams {
     unsigned* tile_counter;
     unsigned long long* stats;
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
-    // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [j*HW + r]
+    // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off;
@@ -233,6 +233,35 @@ struct TraceParams {
     float slab0; int* err_flag; float* cr_lists;
 };
 
+
+// Wave-wide scans on the DPP network (no LDS crossbar round trips): row_shr 1/2/4/8 inside the 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows.  Lanes without a valid source keep `old` (the identity).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_incl_prod(float x)
+{
+    x *= dpp_f<0x111, 0xf>(1.f, x); x *= dpp_f<0x112, 0xf>(1.f, x); x *= dpp_f<0x114, 0xf>(1.f, x); x *= dpp_f<0x118, 0xf>(1.f, x);
+    x *= dpp_f<0x142, 0xa>(1.f, x);          // row_bcast:15 -> rows 1 and 3
+    x *= dpp_f<0x143, 0xc>(1.f, x);          // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ float wave_sum_f(float x)                     // total in every lane
+{
+    x += dpp_f<0x111, 0xf>(0.f, x); x += dpp_f<0x112, 0xf>(0.f, x); x += dpp_f<0x114, 0xf>(0.f, x); x += dpp_f<0x118, 0xf>(0.f, x);
+    x += dpp_f<0x142, 0xa>(0.f, x);
+    x += dpp_f<0x143, 0xc>(0.f, x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_incl_sum(float x)                  // inclusive prefix sum over the 64 lanes
+{
+    x += dpp_f<0x111, 0xf>(0.f, x); x += dpp_f<0x112, 0xf>(0.f, x); x += dpp_f<0x114, 0xf>(0.f, x); x += dpp_f<0x118, 0xf>(0.f, x);
+    x += dpp_f<0x142, 0xa>(0.f, x);
+    x += dpp_f<0x143, 0xc>(0.f, x);
+    return x;
+}
 
 struct RayAcc { float T, C0, C1, C2, Dd, Wt, N0, N1, N2; };
 
@@ -363,13 +392,86 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
     const int n = valid ? min(p.hit_n[r], p.hit_cap) : 0;
     for (int j = 0; __any(j < n); ++j) {
         if (j < n) {
-            const float t = p.hit_t[(size_t)j * p.hw + r];
-            const int g = p.hit_g[(size_t)j * p.hw + r];
-            bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, (size_t)j * p.hw + r);
+            const size_t id = r * (size_t)p.hit_cap + j;
+            const float t = p.hit_t[id];
+            const int g = p.hit_g[id];
+            bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, id);
             if (!SCATTER) {                          // dense (gidx, id) key list for the sort: slot = exclusive_scan(hit_n)[r] + j
                 const unsigned slot = p.hit_off[r] + (unsigned)j;
-                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)((size_t)j * p.hw + r);
+                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
             }
+        }
+    }
+}
+
+// Replay for the sorted-reduction backward, ONE RAY PER WAVE: lane j takes the j-th composited hit of the ray (the
+// record is ray-major, so the loads are coalesced), the transmittance is a wave prefix product and the running sums
+// of the reference's sequential loop (C, D, N "so far", backward.cu:576-604) are wave prefix sums.  131k independent
+// ray tasks instead of 2k waves each walking 64 rays hit by hit.  Writes (t, dL/dalpha, +-w) per hit, the dense
+// (gidx, id) key list and the per-ray pack.
+__global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
+{
+    const int lane = threadIdx.x;
+    const int nsh = p.nsh;
+    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
+    for (unsigned r = blockIdx.x; r < (unsigned)p.hw; r += gridDim.x) {
+        const int n = min(p.hit_n[r], p.hit_cap);
+        if (n == 0) continue;
+        float o[3], d[3], dL[LRT_NCH], fin[LRT_NCH];
+        for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * (size_t)r + i]; d[i] = p.ray_d[3 * (size_t)r + i]; }
+        for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * (size_t)r + i]; fin[i] = p.out9_in[LRT_NCH * (size_t)r + i]; }
+        if (lane < 4) {
+            const float4 v = lane == 0 ? make_float4(o[0], o[1], o[2], dL[3]) : (lane == 1 ? make_float4(d[0], d[1], d[2], 0.f) :
+                             (lane == 2 ? make_float4(dL[0], dL[1], dL[2], 0.f) : make_float4(dL[5], dL[6], dL[7], 0.f)));
+            p.ray_pk[4 * (size_t)r + lane] = v;
+        }
+        const float dL_dbg = dL[0] * bg0 + dL[1] * bg1 + dL[2] * bg2;
+        float b[16];
+        lrt_sh_basis(p.deg, d, b);
+        const unsigned off = p.hit_off[r];
+        float T_run = 1.f, rC0 = 0.f, rC1 = 0.f, rC2 = 0.f, rD = 0.f, rN0 = 0.f, rN1 = 0.f, rN2 = 0.f;
+        for (int cb = 0; cb < n; cb += 64) {
+            const int j = cb + lane;
+            const bool live = j < n;
+            const size_t id = (size_t)r * p.hit_cap + (live ? j : cb);
+            const float t = p.hit_t[id];
+            const int g = p.hit_g[id];
+            const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
+            const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
+            const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
+            const float op = p.opac[g];
+            float c0, c1, c2; bool cl0;
+            sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
+            LrtHitGeom hg;
+            lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+            const float ao = op * hg.G;
+            const float alpha = fminf(LRT_ALPHA_MAX, ao);
+            const float incl = wave_incl_prod(live ? (1.f - alpha) : 1.f);
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            const float Tk = T_run * excl;
+            const float wgt = live ? alpha * Tk : 0.f;
+            const float n0 = hg.R[2], n1 = hg.R[5], n2 = hg.R[8];
+            const float sC0 = rC0 + wave_incl_sum(wgt * c0), sC1 = rC1 + wave_incl_sum(wgt * c1), sC2 = rC2 + wave_incl_sum(wgt * c2);
+            const float sD = rD + wave_incl_sum(wgt * t);
+            const float sN0 = rN0 + wave_incl_sum(wgt * n0), sN1 = rN1 + wave_incl_sum(wgt * n1), sN2 = rN2 + wave_incl_sum(wgt * n2);
+            const float i1a = 1.0f / (1.0f - alpha);
+            float dLa = dL[0] * (Tk * c0 - (fin[0] - sC0) * i1a) + dL[1] * (Tk * c1 - (fin[1] - sC1) * i1a) +
+                        dL[2] * (Tk * c2 - (fin[2] - sC2) * i1a);
+            dLa += dL_dbg * (-fin[8] * i1a);                        // D1 (backward.cu:595-598)
+            dLa += dL[3] * (Tk * t - (fin[3] - sD) * i1a);
+            dLa += dL[5] * (Tk * n0 - (fin[5] - sN0) * i1a) + dL[6] * (Tk * n1 - (fin[6] - sN1) * i1a) +
+                   dL[7] * (Tk * n2 - (fin[7] - sN2) * i1a);        // D3
+            dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
+            if (live) {
+                p.hit_pk[id] = make_float4(t, dLa, cl0 ? -wgt : wgt, 0.f);
+                const unsigned slot = off + (unsigned)j;
+                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
+            }
+            // carries for rays with more than 64 composited hits
+            T_run *= rdl(incl, 63);
+            rC0 = rdl(sC0, 63); rC1 = rdl(sC1, 63); rC2 = rdl(sC2, 63); rD = rdl(sD, 63);
+            rN0 = rdl(sN0, 63); rN1 = rdl(sN1, 63); rN2 = rdl(sN2, 63);
         }
     }
 }
@@ -422,7 +524,7 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
 #pragma unroll
             for (int k = 0; k < 48; k++) ash[k] = 0.f;
         }
-        const unsigned r = id % (unsigned)p.hw;
+        const unsigned r = id / (unsigned)p.hit_cap;
         const float4 hp = p.hit_pk[id];
         const float t = hp.x, da = hp.y, ws = hp.z;
         const float w = fabsf(ws);
@@ -478,7 +580,7 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
 #pragma unroll
     for (int k = 0; k < 48; k++) ash[k] = 0.f;
     if (live) {
-        const unsigned r = id % (unsigned)p.hw;
+        const unsigned r = id / (unsigned)p.hit_cap;
         const float4 hp = p.hit_pk[id];
         const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
         const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
@@ -733,7 +835,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
                                 unsafeAtomicAdd(p.accum + g, wgt);                      // forward.cu:268
                                 if (p.hit_t) {                                          // record for the replay backward
                                     if (n_rec < p.hit_cap) {
-                                        const size_t id = (size_t)n_rec * p.hw + r;
+                                        const size_t id = r * (size_t)p.hit_cap + n_rec;
                                         p.hit_t[id] = t; p.hit_g[id] = g;
                                     }
                                     n_rec++;
@@ -1218,7 +1320,11 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 { size_t sb = st->scan_tmp_bytes;
                   HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
                 tp.hit_off = st->hit_off; tp.hit_keys = st->hit_keys; tp.key_cap = st->key_cap;
-                hipLaunchKernelGGL(k_bwd_replay<false>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+                {
+                    const int hw = H * W;
+                    const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
+                    hipLaunchKernelGGL(k_bwd_prep, dim3(blocks), dim3(64), 0, stream, tp);
+                }
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
                     size_t tmpb = st->bsort_tmp_bytes;
