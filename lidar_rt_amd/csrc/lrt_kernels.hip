@@ -973,7 +973,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 8.0f;
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;
     if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
