@@ -80,6 +80,11 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                  const float* dL_dout9, float* d_means, float* d_shs, float* d_opacities, float* d_scales,
                  float* d_rotations, void* stream);
 
+/* Serial number of the most recent lrt_forward on this state.  The composited-hit record that the replay backward
+ * uses belongs to THAT forward: a caller that runs several forwards before a backward compares the serial it saved
+ * and, on mismatch, sets option "invalidate_record" so that lrt_backward re-traces instead. */
+long long lrt_forward_serial(lrt_state* st);
+
 /* Optional instrumentation: when enabled, lrt_forward accumulates
  * stats[0] = candidate hits consumed, stats[1] = composited hits, stats[2] = traversal passes (ray-tile restarts),
  * stats[3] = BVH nodes visited (wave level), stats[4] = leaf primitives tested (wave level)

@@ -65,6 +65,7 @@ struct lrt_state {
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
+    long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
@@ -1031,6 +1032,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->tile16_w_log2 = l2; return LRT_OK;
     }
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
+    if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
     if (!strcmp(name, "reduce_mode")) { st->reduce_mode = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
         if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
@@ -1044,6 +1046,9 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     }
     LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: unknown option '%s'", name);
 }
+
+/* Serial number of the most recent lrt_forward on this state (the hit record belongs to that forward). */
+long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
 
 int lrt_enable_timing(lrt_state* st, int enable)
 {
@@ -1202,6 +1207,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
     st->hits_valid = 0;
+    st->fwd_serial++;
     const size_t HW = (size_t)H * W;
     const bool record = training && st->replay_enabled && HW > 0 && P > 0;
     if (record) {

@@ -198,13 +198,14 @@ def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertic
         _capi.check(state._lib.lrt_forward(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
                                            _capi.ptr(sh), _capi.ptr(bg), 1 if training else 0, _capi.ptr(out),
                                            _capi.ptr(out_i), _capi.ptr(accum), _stream_ptr()), "lrt_forward")
+    state.last_serial = int(state._lib.lrt_forward_serial(h))
     return out, out_i, accum
 
 
 def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, background, means3D, shs,
                            degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
                            transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
-                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None):
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None):
     # grads_out (extension): dict of preallocated contiguous fp32 tensors 'means' (P,3), 'shs' (P,M,3), 'opacities' (P,1),
     # 'scales' (P,2), 'rotations' (P,4) to write into (e.g. views of one flat buffer for a fused all-reduce)
     P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
@@ -215,6 +216,9 @@ def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, bac
     idx, h = state.handle(dev)
     if state._built_P.get(idx, -1) != P:
         raise RuntimeError("trace_surfels_backward: acceleration structure does not match (run forward first)")
+    if forward_serial is not None and int(state._lib.lrt_forward_serial(h)) != forward_serial:
+        # another forward ran on this state since: its hit record replaced ours -> re-trace like the reference
+        _capi.check(state._lib.lrt_set_option(h, b"invalidate_record", 1), "lrt_set_option")
     ro, rd = ray_o.detach().contiguous(), ray_d.detach().contiguous()
     bg = background.detach().contiguous()
     m, s, r, o, sh = (means3D.detach().contiguous(), scales.detach().contiguous(), rotations.detach().contiguous(),

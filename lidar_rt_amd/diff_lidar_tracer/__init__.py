@@ -44,6 +44,7 @@ class _Tracer(torch.autograd.Function):
             ts.prefiltered, ts.debug)
         ctx.tracer_settings = ts
         ctx.state = state
+        ctx.forward_serial = getattr(state, "last_serial", None)
         ctx.save_for_backward(ray_o, ray_d, vertices, means3D, shs, colors_precomp, opacities, scales, rotations,
                               cov3Ds_precomp, out_f32, out_i32)
         ctx.mark_non_differentiable(accum)
@@ -57,7 +58,7 @@ class _Tracer(torch.autograd.Function):
         (g_means, g_shs, g_colors, g_opac, g_scales, g_rot, g_cov, g_g3) = _C.trace_surfels_backward(
             ctx.state, ray_o, ray_d, vertices, ts.bg, means3D, shs, ts.sh_degree, colors_precomp, opacities, scales,
             ts.scale_modifier, rotations, cov3Ds_precomp, ts.viewmatrix, ts.projmatrix, ts.campos, ts.prefiltered,
-            ts.debug, out_f32, out_i32, grad_out_f32)
+            ts.debug, out_f32, out_i32, grad_out_f32, forward_serial=ctx.forward_serial)
         g_opac = g_opac.reshape(opacities.shape)
         g_colors = g_colors if colors_precomp.numel() > 0 else None
         g_cov = g_cov if cov3Ds_precomp.numel() > 0 else None

@@ -212,3 +212,22 @@ def test_s1m_full_size_parity_and_invariants(golden_dir):
     for k in ("means", "opacities", "shs"):
         lin = 2.0 * h["grads"][k] - 0.5 * h2["grads"][k]
         assert rel_l2(h3["grads"][k], lin) < 1e-4
+
+
+def test_two_forwards_before_backward(s10k):
+    """The hit record belongs to the LAST forward; the backward of an earlier forward must notice and re-trace."""
+    from lidar_rt_amd.diff_lidar_tracer import Tracer
+    from tests.hip_util import settings, DEV
+    sc, o, d, dL = s10k
+    fw, bw = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    tr = Tracer()
+    t = {k: torch.as_tensor(v, device=DEV).requires_grad_(True) for k, v in sc.items()}
+    ro, rd = torch.as_tensor(o, device=DEV), torch.as_tensor(d, device=DEV)
+    ts = settings(scenes.BG_DEFAULT, 3)
+    tr.build_from_gaussians(t["means"], t["scales"], t["rotations"], t["opacities"])
+    kw = dict(shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], tracer_settings=ts)
+    out1, _ = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), **kw)
+    out2, _ = tr(ro[:8], rd[:8], None, t["means"], torch.zeros_like(t["means"]), **kw)      # a different ray set in between
+    out1.backward(torch.as_tensor(dL, device=DEV))
+    for k in GRADS:
+        assert rel_l2(t[k].grad.cpu().numpy().reshape(bw[k].shape), bw[k]) < 1e-3
