@@ -63,7 +63,7 @@ struct lrt_state {
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
-    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes;
+    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float* hit_w; int defer_colour;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
@@ -225,6 +225,7 @@ struct TraceParams {
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
+    float* hit_w;          // composite weights of the recorded hits (deferred-colour forward)
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off;
     const unsigned long long* sorted_keys; unsigned n_hits;
@@ -974,7 +975,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;
     if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
@@ -1002,7 +1003,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_w); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1032,6 +1033,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->tile16_w_log2 = l2; return LRT_OK;
     }
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
+    if (!strcmp(name, "defer_colour")) { st->defer_colour = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
     if (!strcmp(name, "reduce_mode")) { st->reduce_mode = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
@@ -1209,18 +1211,20 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     st->hits_valid = 0;
     st->fwd_serial++;
     const size_t HW = (size_t)H * W;
-    const bool record = training && st->replay_enabled && HW > 0 && P > 0;
+    const bool defer = st->fwd_mode == 1 && st->defer_colour;                 // the colour pass reads the hit record
+    const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
-            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp};
+            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp, st->hit_w};
             for (void* q : olds) (void)hipFree(q);
             st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
-            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0; st->hit_off = nullptr; st->scan_tmp = nullptr;
+            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0; st->hit_off = nullptr; st->scan_tmp = nullptr; st->hit_w = nullptr;
             const size_t nrec = HW * (size_t)st->hit_cap;
             if (nrec >= (1ull << 32)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: H*W*hit_cap exceeds 2^32 (lower the hit_cap option)");
             HIPCHK(hipMalloc(&st->hit_t, nrec * sizeof(float)));
             HIPCHK(hipMalloc(&st->hit_g, nrec * sizeof(int)));
+            HIPCHK(hipMalloc(&st->hit_w, nrec * sizeof(float)));
             HIPCHK(hipMalloc(&st->hit_pk, nrec * sizeof(float4)));
             HIPCHK(hipMalloc(&st->ray_pk, HW * 4 * sizeof(float4)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
@@ -1240,7 +1244,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         HIPCHK(hipMemsetAsync(st->hit_ovf, 0, sizeof(int), stream));
         HIPCHK(hipMemsetAsync(st->hit_count, 0, sizeof(unsigned), stream));
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
-        tp.hit_cap = st->hit_cap; tp.hw = (int)HW;
+        tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_w = st->hit_w;
         tp.hit_count = st->hit_count;
     }
     if (st->fwd_mode == 1) {
@@ -1252,17 +1256,23 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
-            int blocks = tp.n_tiles < 256 * 12 ? tp.n_tiles : 256 * 12;          // persistent single-wave workgroups
+            int blocks = tp.n_tiles < 256 * 16 ? tp.n_tiles : 256 * 16;          // persistent single-wave workgroups (4 per SIMD)
             if (blocks > st->cr_blocks_cap) {
                 HIPCHK(hipStreamSynchronize(stream));
                 (void)hipFree(st->cr_lists); st->cr_lists = nullptr; st->cr_blocks_cap = 0;
-                const int cap = blocks < 256 ? 256 : 256 * 12;
+                const int cap = blocks < 256 ? 256 : 256 * 16;
                 HIPCHK(hipMalloc(&st->cr_lists, (size_t)cap * CR_LIST_WORDS * sizeof(float)));
                 st->cr_blocks_cap = cap;
             }
             tp.cr_lists = st->cr_lists;
             ScopedTimer tm(st, 1, stream);
-            hipLaunchKernelGGL(k_fwd_cr, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+            if (defer && record) {
+                hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+                const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
+                hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
+            } else {
+                hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+            }
         }
         HIPCHK(hipGetLastError());
     } else {
@@ -1274,7 +1284,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->hit_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 1, st->hit_count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipEventRecord(st->hit_ev, stream));
-        st->hits_valid = 1; st->hit_H = H; st->hit_W = W;
+        st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
     }
     return LRT_OK;
 }
