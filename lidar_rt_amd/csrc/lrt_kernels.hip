@@ -975,7 +975,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->defer_colour = 0; st->tile16_w_log2 = 2; st->slab0 = 16.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
@@ -1028,8 +1028,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 or 1"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
         int l2 = -1;
-        for (int i = 0; i <= 4; i++) if ((1 << i) == value) l2 = i;
-        if (l2 < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: tile16_w must be 1, 2, 4, 8 or 16");
+        for (int i = 0; i <= 4; i++) if ((1 << i) == value && value <= CR_RAYS) l2 = i;
+        if (l2 < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: tile16_w must be a power of two <= %d", CR_RAYS);
         st->tile16_w_log2 = l2; return LRT_OK;
     }
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
@@ -1247,6 +1247,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_w = st->hit_w;
         tp.hit_count = st->hit_count;
     }
+    HIPCHK(hipMemsetAsync(st->err_flag, 0, sizeof(int), stream));
     if (st->fwd_mode == 1) {
         const int TW = 1 << st->tile16_w_log2, TH = CR_RAYS / TW;
         tp.tw_log2 = st->tile16_w_log2;
@@ -1317,7 +1318,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow (more than 256 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0");
+        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list, 2 = BVH stack] (more than 256 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0", st->hit_ovf_host[2]);
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
         if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
