@@ -227,7 +227,7 @@ struct TraceParams {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     float* hit_w;          // composite weights of the recorded hits (deferred-colour forward)
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
-    unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off;
+    unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
     const unsigned long long* sorted_keys; unsigned n_hits;
     float4* hit_pk;        // per hit (t, dL/dalpha, +-w, -) written by k_bwd_replay<false>, one 16-B gather in k_bwd_reduce
     float4* ray_pk;        // per ray 4 x float4: (o, dL3) (d, -) (dL0..2, -) (dL5..7, -)
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
             bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, id);
             if (!SCATTER) {                          // dense (gidx, id) key list for the sort: slot = exclusive_scan(hit_n)[r] + j
                 const unsigned slot = p.hit_off[r] + (unsigned)j;
-                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
+                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << p.id_bits) | (unsigned long long)id;
             }
         }
     }
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
             if (live) {
                 p.hit_pk[id] = make_float4(t, dLa, cl0 ? -wgt : wgt, 0.f);
                 const unsigned slot = off + (unsigned)j;
-                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << 32) | (unsigned long long)id;
+                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << p.id_bits) | (unsigned long long)id;
             }
             // carries for rays with more than 64 composited hits
             T_run *= rdl(incl, 63);
@@ -513,12 +513,12 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
     };
     for (unsigned long long i = i0; i < i1; ++i) {
         const unsigned long long key = p.sorted_keys[i];
-        const int g = (int)(key >> 32);
-        const unsigned id = (unsigned)key;
+        const int g = (int)(key >> p.id_bits);
+        const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
         if (g != cur) {
             if (cur >= 0) flush(cur, shared);
             cur = g;
-            shared = (i == i0) && (i0 > 0) && ((int)(p.sorted_keys[i0 - 1] >> 32) == g);
+            shared = (i == i0) && (i0 > 0) && ((int)(p.sorted_keys[i0 - 1] >> p.id_bits) == g);
             for (int k = 0; k < 3; k++) { mu[k] = p.means[3 * (size_t)g + k]; am[k] = 0.f; }
             for (int k = 0; k < 2; k++) { sc[k] = p.scales[2 * (size_t)g + k]; as[k] = 0.f; }
             for (int k = 0; k < 4; k++) { q[k] = p.rots[4 * (size_t)g + k]; ar[k] = 0.f; }
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
             if (k < nsh) { ash[3 * k] += b[k] * r0; ash[3 * k + 1] += b[k] * r1; ash[3 * k + 2] += b[k] * r2; }
     }
     if (cur >= 0) {
-        const bool cont = (i1 < p.n_hits) && ((int)(p.sorted_keys[i1] >> 32) == cur);
+        const bool cont = (i1 < p.n_hits) && ((int)(p.sorted_keys[i1] >> p.id_bits) == cur);
         flush(cur, shared || cont);
     }
 }
@@ -573,8 +573,8 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
     const bool live = i < p.n_hits;
     const unsigned long long wave0 = i - (unsigned long long)lane;
     const unsigned long long key = live ? p.sorted_keys[i] : ~0ull;
-    const int g = (int)(key >> 32);
-    const unsigned id = (unsigned)key;
+    const int g = live ? (int)(key >> p.id_bits) : -1;
+    const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
     const int nsh = p.nsh;
     float acc[10], ash[48];
 #pragma unroll
@@ -627,8 +627,8 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
     const bool starts_at0 = (63 - __clzll((long long)below)) == 0;
     if (!tail) return;
     bool shared = false;
-    if (starts_at0 && wave0 > 0) shared = ((int)(p.sorted_keys[wave0 - 1] >> 32) == g);
-    if (lane == 63 && i + 1 < p.n_hits) shared = shared || ((int)(p.sorted_keys[i + 1] >> 32) == g);
+    if (starts_at0 && wave0 > 0) shared = ((int)(p.sorted_keys[wave0 - 1] >> p.id_bits) == g);
+    if (lane == 63 && i + 1 < p.n_hits) shared = shared || ((int)(p.sorted_keys[i + 1] >> p.id_bits) == g);
     float* dm = p.d_means + 3 * (size_t)g; float* ds = p.d_scales + 2 * (size_t)g; float* dr = p.d_rots + 4 * (size_t)g;
     float* dsh = p.d_shs + (size_t)g * p.M * 3;
     if (shared) {
@@ -1336,7 +1336,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk;
                 { size_t sb = st->scan_tmp_bytes;
                   HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
-                tp.hit_off = st->hit_off; tp.hit_keys = st->hit_keys; tp.key_cap = st->key_cap;
+                int id_bits = 1; while ((1ull << id_bits) < (unsigned long long)H * W * (unsigned long long)tp.hit_cap) id_bits++;
+                tp.hit_off = st->hit_off; tp.hit_keys = st->hit_keys; tp.key_cap = st->key_cap; tp.id_bits = id_bits;
                 {
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
@@ -1345,7 +1346,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
                     size_t tmpb = st->bsort_tmp_bytes;
-                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, 0, 32 + gbits, stream));
+                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, 0, id_bits + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
                     if (st->reduce_mode == 0) {
                         const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
