@@ -53,9 +53,14 @@ def cpu_baseline(sc, ray_o, ray_d, deg, bg, dL, col_stride=8):
         if probe["seconds"] >= 2.0:
             probe["sample"] = f"every {col_stride}th azimuth column of the frame: " + probe["sample"]
             return probe
-        full = cpu_baseline(sc, ray_o, ray_d, deg, bg, dL, 1)
-        full["sample"] = "whole frame: " + full["sample"]
-        return full
+        # fast host: repeat the whole frame until ~10 s of CPU work have been timed
+        reps, tot_s, tot_rays, last = 0, 0.0, 0, None
+        while tot_s < 10.0 and reps < 12:
+            last = cpu_baseline(sc, ray_o, ray_d, deg, bg, dL, 1)
+            tot_s += last["seconds"]; tot_rays += ray_o.shape[0] * ray_o.shape[1]; reps += 1
+        last["value"] = tot_rays / tot_s; last["seconds"] = tot_s
+        last["sample"] = f"whole frame x{reps} ({tot_s:.1f} s of CPU work); last repetition: " + last["sample"]
+        return last
     o = np.ascontiguousarray(ray_o[:, ::col_stride]); d = np.ascontiguousarray(ray_d[:, ::col_stride])
     g = np.ascontiguousarray(dL[:, ::col_stride])
     t0 = time.time()

@@ -80,7 +80,7 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 
         traffic[k] = {"hbm_bytes_per_launch": corr * 1e6, "fetch_kb": fs, "write_kb": ws, "raw_bytes_per_launch": raw * 1e6}
 
 # labels bench.py uses for the dominant kernel
-fwd = traffic.get("k_fwd_cr")
+fwd = next((v for k, v in traffic.items() if k.startswith("k_fwd_cr")), None)
 if fwd:
     traffic["k_fwd_cr (collect & resolve forward)"] = fwd
 bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
