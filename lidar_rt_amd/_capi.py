@@ -13,7 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
 
 EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_forward",
-           "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial")
+           "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial",
+           # include/lrt_chamfer.h
+           "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
+           "lrt_chamfer_set_option")
 
 _lib = None
 
@@ -51,6 +54,13 @@ def load():
     lib.lrt_forward_serial.restype = C.c_longlong; lib.lrt_forward_serial.argtypes = [vp]
     lib.lrt_debug_read.restype = C.c_longlong; lib.lrt_debug_read.argtypes = [vp, ci, vp, C.c_longlong, vp]
     lib.lrt_set_option.restype = ci; lib.lrt_set_option.argtypes = [vp, C.c_char_p, ci]
+    lib.lrt_chamfer_create.restype = vp; lib.lrt_chamfer_create.argtypes = [ci]
+    lib.lrt_chamfer_destroy.restype = None; lib.lrt_chamfer_destroy.argtypes = [vp]
+    lib.lrt_chamfer_forward.restype = ci
+    lib.lrt_chamfer_forward.argtypes = [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.lrt_chamfer_backward.restype = ci
+    lib.lrt_chamfer_backward.argtypes = [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.lrt_chamfer_set_option.restype = ci; lib.lrt_chamfer_set_option.argtypes = [vp, C.c_char_p, ci]
     if lib.lrt_abi_version() != 1:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
     _lib = lib

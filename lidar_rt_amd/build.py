@@ -13,8 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblrt_hip.so")
-SOURCES = ["lrt_kernels.hip"]
-HEADERS = ["lrt_math.h", "lrt_collect.inc", os.path.join("..", "..", "include", "lrt.h")]
+SOURCES = ["lrt_kernels.hip", "lrt_chamfer.hip"]
+HEADERS = ["lrt_math.h", "lrt_collect.inc", os.path.join("..", "..", "include", "lrt.h"),
+           os.path.join("..", "..", "include", "lrt_chamfer.h")]
 ARCH = "gfx950"
 
 

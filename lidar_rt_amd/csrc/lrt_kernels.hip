@@ -961,6 +961,8 @@ extern "C" {
 
 int lrt_abi_version(void) { return 1; }
 const char* lrt_last_error(void) { return g_err; }
+// the same buffer for the other translation units of this library (lrt_chamfer.hip); not part of the ABI
+__attribute__((visibility("hidden"))) char* lrt_internal_errbuf(void) { return g_err; }
 
 lrt_state* lrt_create(int device)
 {

@@ -1,0 +1,93 @@
+/*
+ * chamfer_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * CPU restatement ("oracle") of the reference's Chamfer-distance extension
+ * (zju3dv/LiDAR-RT lib/utils/chamfer3D/chamfer3D.cu).  Only tests/,
+ * __graft_entry__.smoke() and bench tools' cpu_baseline legs may load it.
+ *
+ * What it follows
+ *   orc_chamfer_forward   NmDistanceKernel, chamfer3D.cu:11-133, launched for both directions (:141-142):
+ *                         for every query the candidates are scanned in index order, the pair distance is
+ *                         (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 in float32 (:31-34) and a candidate replaces the best only
+ *                         when `d < best` (strict; `k==0 ||` seeds a tile with its first candidate :35, and
+ *                         `k2==0 || result > best` merges tiles strictly :124), i.e. the FIRST minimum wins.
+ *   orc_chamfer_backward  NmDistanceGradKernel, chamfer3D.cu:154-173, both directions (:183-184):
+ *                         g = 2*grad_dist; grad_self += g*(self-other); grad_other[idx] -= g*(self-other).
+ *                         The reference accumulates with float atomics in arbitrary order; the oracle adds in
+ *                         index order (direction 1 first) in float32, or in float64 (the *_f64 entry).
+ *
+ * Arithmetic: nvcc compiles :34 with fp contraction on; the chain is restated as
+ * fmaf(dz,dz, fmaf(dy,dy, dx*dx)).  The other legal contraction, fmaf(dz,dz, fmaf(dx,dx, dy*dy)), differs by at
+ * most 1 ulp of the result; orc_chamfer_forward's `variant` argument selects it (1) or no contraction (2) so that
+ * tests can show the index set is insensitive to it away from exact near-ties.
+ *
+ * PARITY PINNING: the reference ships no test, fixture or Python fallback for this extension and its kernels are
+ * CUDA-only, so they cannot be run here: "parity unpinned" against the CUDA binary.  The oracle is pinned instead
+ * against the mathematical definition (float64 brute force via numpy in tests/test_chamfer_oracle.py) and against
+ * the autograd contract of dist_chamfer_3D.py:31-82 (finite differences of the summed distances).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+
+static inline float d2_v0(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+static inline float d2_v1(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dx, dx, dy * dy)); }
+static inline float d2_v2(float dx, float dy, float dz) { float a = dx * dx; float b = dy * dy; float c = dz * dz; float s = a + b; return s + c; }
+
+static void nn_dir(int n, const float* q, int m, const float* c, float* dist, int32_t* idx, int variant)
+{
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n; j++) {
+        const float x1 = q[3 * (size_t)j], y1 = q[3 * (size_t)j + 1], z1 = q[3 * (size_t)j + 2];
+        float best = 0.f; int best_i = 0;
+        for (int k = 0; k < m; k++) {
+            const float x2 = c[3 * (size_t)k] - x1, y2 = c[3 * (size_t)k + 1] - y1, z2 = c[3 * (size_t)k + 2] - z1;
+            const float d = variant == 0 ? d2_v0(x2, y2, z2) : variant == 1 ? d2_v1(x2, y2, z2) : d2_v2(x2, y2, z2);
+            if (k == 0 || d < best) { best = d; best_i = k; }
+        }
+        dist[j] = best; idx[j] = best_i;
+    }
+}
+
+void orc_chamfer_forward(int B, int N, const float* xyz1, int M, const float* xyz2, float* dist1, float* dist2,
+                         int32_t* idx1, int32_t* idx2, int variant)
+{
+    for (int b = 0; b < B; b++) {
+        nn_dir(N, xyz1 + (size_t)b * N * 3, M, xyz2 + (size_t)b * M * 3, dist1 + (size_t)b * N, idx1 + (size_t)b * N, variant);
+        nn_dir(M, xyz2 + (size_t)b * M * 3, N, xyz1 + (size_t)b * N * 3, dist2 + (size_t)b * M, idx2 + (size_t)b * M, variant);
+    }
+}
+
+#define GRAD_DIR(T)                                                                                                   \
+    for (int j = 0; j < n; j++) {                                                                                     \
+        const int j2 = idx[j];                                                                                        \
+        const float g = gd[j] * 2;                                                                                    \
+        for (int a = 0; a < 3; a++) {                                                                                 \
+            const float t = g * (self[3 * (size_t)j + a] - other[3 * (size_t)j2 + a]);                                \
+            gself[3 * (size_t)j + a] += (T)t;                                                                         \
+            gother[3 * (size_t)j2 + a] += (T)(-t);                                                                    \
+        }                                                                                                             \
+    }
+
+static void grad_dir_f32(int n, const float* self, const float* other, const float* gd, const int32_t* idx, float* gself, float* gother) { GRAD_DIR(float) }
+static void grad_dir_f64(int n, const float* self, const float* other, const float* gd, const int32_t* idx, double* gself, double* gother) { GRAD_DIR(double) }
+
+/* gradxyz buffers are accumulated into, like the reference binding (dist_chamfer_3D.py:67-73 passes zeros). */
+void orc_chamfer_backward_f32(int B, int N, const float* xyz1, int M, const float* xyz2, const float* gd1, const float* gd2,
+                              const int32_t* idx1, const int32_t* idx2, float* g1, float* g2)
+{
+    for (int b = 0; b < B; b++) {
+        const float *a = xyz1 + (size_t)b * N * 3, *c = xyz2 + (size_t)b * M * 3;
+        grad_dir_f32(N, a, c, gd1 + (size_t)b * N, idx1 + (size_t)b * N, g1 + (size_t)b * N * 3, g2 + (size_t)b * M * 3);
+        grad_dir_f32(M, c, a, gd2 + (size_t)b * M, idx2 + (size_t)b * M, g2 + (size_t)b * M * 3, g1 + (size_t)b * N * 3);
+    }
+}
+
+void orc_chamfer_backward_f64(int B, int N, const float* xyz1, int M, const float* xyz2, const float* gd1, const float* gd2,
+                              const int32_t* idx1, const int32_t* idx2, double* g1, double* g2)
+{
+    for (int b = 0; b < B; b++) {
+        const float *a = xyz1 + (size_t)b * N * 3, *c = xyz2 + (size_t)b * M * 3;
+        grad_dir_f64(N, a, c, gd1 + (size_t)b * N, idx1 + (size_t)b * N, g1 + (size_t)b * N * 3, g2 + (size_t)b * M * 3);
+        grad_dir_f64(M, c, a, gd2 + (size_t)b * M, idx2 + (size_t)b * M, g2 + (size_t)b * M * 3, g1 + (size_t)b * N * 3);
+    }
+}

@@ -19,7 +19,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("lrt_oracle.c", "lrt_oracle_impl.inc")]
+    src = [os.path.join(_HERE, f) for f in ("lrt_oracle.c", "lrt_oracle_impl.inc", "chamfer_oracle.c")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
     if force or stale:

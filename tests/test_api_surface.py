@@ -18,12 +18,15 @@ def lib():
 
 
 def test_library_exports_every_symbol_the_header_declares(lib):
-    hdr = open(os.path.join(REPO, "include", "lrt.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(lrt_[a-z_0-9]+)\s*\(", hdr))
-    assert {"lrt_create", "lrt_destroy", "lrt_build", "lrt_forward", "lrt_backward", "lrt_last_error"} <= names
+    names = set()
+    for h in ("lrt.h", "lrt_chamfer.h"):
+        hdr = open(os.path.join(REPO, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(lrt_[a-z_0-9]+)\s*\(", hdr))
+    assert {"lrt_create", "lrt_destroy", "lrt_build", "lrt_forward", "lrt_backward", "lrt_last_error",
+            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward"} <= names
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/lrt.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert set(_capi.EXPORTS) <= names
     assert lib.lrt_abi_version() == 1
 
@@ -73,5 +76,28 @@ def test_no_cpu_fallback():
     import lidar_rt_amd
     src = "".join(open(os.path.join(os.path.dirname(lidar_rt_amd.__file__), f)).read()
                   for f in ("_capi.py", "parallel.py", "renderer.py", os.path.join("diff_lidar_tracer", "_C.py"),
-                            os.path.join("diff_lidar_tracer", "__init__.py")))
+                            os.path.join("diff_lidar_tracer", "__init__.py"), os.path.join("chamfer3D", "_C.py"),
+                            os.path.join("chamfer3D", "dist_chamfer_3D.py"), os.path.join("chamfer3D", "__init__.py")))
     assert "oracle" not in src.replace("oracle-backed", "")         # product code never imports the checker
+
+
+def test_chamfer_surface_matches_reference(lib):
+    """lib/utils/chamfer3D/dist_chamfer_3D.py:31-82 and the pybind module of chamfer_cuda.cpp:29-32."""
+    import importlib.util
+    import inspect
+    assert importlib.util.find_spec("chamfer_3D") is not None      # what dist_chamfer_3D.py:8 probes before JIT-compiling
+    import chamfer_3D
+    assert list(inspect.signature(chamfer_3D.forward).parameters) == ["xyz1", "xyz2", "dist1", "dist2", "idx1", "idx2"]
+    assert list(inspect.signature(chamfer_3D.backward).parameters) == [
+        "xyz1", "xyz2", "gradxyz1", "gradxyz2", "graddist1", "graddist2", "idx1", "idx2"]
+    from lidar_rt_amd.chamfer3D.dist_chamfer_3D import chamfer_3DDist, chamfer_3DFunction
+    assert issubclass(chamfer_3DFunction, torch.autograd.Function)
+    m = chamfer_3DDist()
+    assert isinstance(m, torch.nn.Module) and list(inspect.signature(m.forward).parameters) == ["input1", "input2"]
+    with pytest.raises(RuntimeError, match="HIP|cuda"):            # no CPU path
+        m(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))
+    if not torch.cuda.is_available():
+        assert not lib.lrt_chamfer_create(0)
+        assert b"no HIP device" in lib.lrt_last_error()
+    assert lib.lrt_chamfer_forward(None, 1, 1, None, 1, None, None, None, None, None, None) != 0
+    assert b"null state" in lib.lrt_last_error()
