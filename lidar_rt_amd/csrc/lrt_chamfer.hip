@@ -27,12 +27,21 @@
 #include "../../include/lrt.h"
 #include "../../include/lrt_chamfer.h"
 
+#ifndef CH_MERGE_LIMIT
+#define CH_MERGE_LIMIT (1024 * 1024)
+#endif
+#ifndef CH_TOP_MAX
+#define CH_TOP_MAX 512
+#endif
+
 extern "C" __attribute__((visibility("hidden"))) char* lrt_internal_errbuf(void);          // lrt_kernels.hip: the thread-local buffer behind lrt_last_error()
 #define CH_ERRLEN 512
 #define CH_FAIL(code, ...) do { snprintf(lrt_internal_errbuf(), CH_ERRLEN, __VA_ARGS__); return (code); } while (0)
 #define CH_HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     CH_FAIL(LRT_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
+// rocPRIM sorts up to CH_MERGE_LIMIT keys with its merge sort (measured faster than onesweep at 2 x 111k keys)
+using ch_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, CH_MERGE_LIMIT>;
 #define CH_MAXL 12
 #define CH_EMPTY 1e30f          // empty box / padding point: bound and distance overflow to +inf, never <= best
 #define CH_BIG 3.0e38f          // initial best (any finite pair distance is smaller)
@@ -219,10 +228,10 @@ __global__ __launch_bounds__(CH_QBLOCK) void kc_query(ChParams p, int depth)
     const int tid = blockIdx.x * CH_QBLOCK + threadIdx.x;
     if (tid >= p.n[0] + p.n[1]) return;
     const int dir = tid >= p.n[0];
-    const int qi = tid - (dir ? p.n[0] : 0);
     const ChTree& T = p.t[1 - dir];
-    const float* qp = p.xyz[dir] + 3 * (size_t)qi;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float4 q4 = p.pts[p.t[dir].pts_off + tid - (dir ? p.n[0] : 0)];      // queries in Morton order: neighbouring lanes walk alike
+    const int qi = __float_as_int(q4.w);
+    const float qx = q4.x, qy = q4.y, qz = q4.z;
     const float4* __restrict__ pts = p.pts + T.pts_off;
     const float* __restrict__ boxes = p.boxes;
     unsigned long long* stk = s_stack + threadIdx.x;
@@ -270,6 +279,139 @@ __global__ __launch_bounds__(CH_QBLOCK) void kc_query(ChParams p, int depth)
     }
     p.dist[dir][qi] = best;
     p.idx[dir][qi] = besti;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Packet search (default tree kernel): one WAVEFRONT owns 64 Morton-consecutive queries (the other cloud's sorted
+// points) and walks the tree once for all of them.  The traversal state is wave-uniform, so box blocks and leaf points
+// come through scalar loads (s_load_dwordx16 -> SGPR operands, every byte fetched once per 64 queries instead of once
+// per lane) and branches are `__ballot`s; each lane keeps its own (best, idx).  A box is visited while ANY lane has
+// bound <= best; visiting more boxes than a lane needs only adds candidates a brute-force scan would also see, so
+// the result stays bit-identical.  Per-lane bounds of postponed children sit in an LDS stack ([depth][64] floats +
+// the uniform entry word) so that a popped entry nobody needs any more costs one ds_read + ballot.
+#define CH_PK_WAVES 4
+#ifndef CH_LEAF_LDS
+#define CH_LEAF_LDS 0
+#endif
+#ifndef CH_KEY64
+#define CH_KEY64 1
+#endif
+__global__ __launch_bounds__(64 * CH_PK_WAVES) void kc_query_pk(ChParams p, const float* __restrict__ boxes,
+                                                                const float4* __restrict__ pts, int depth)
+{
+    extern __shared__ float s_pk[];                          // per wave: 64 float4 leaf points, depth x 64 bounds, depth entry words
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * CH_PK_WAVES + wib);
+    const int nw0 = p.t[1].pts_off >> 6;                     // waves whose queries are cloud 0's points
+    const int nw1 = (((p.t[1].n_lvl[1] + 7) / 8) * 64) >> 6;
+    if (wave >= nw0 + nw1) return;
+    const int dir = wave >= nw0;
+    const ChTree& Q = p.t[dir];                              // the queries' own cloud
+    const ChTree& T = p.t[1 - dir];                          // the cloud searched
+    const int s0 = (wave - (dir ? nw0 : 0)) * 64;
+    const bool valid = s0 + lane < Q.n;
+    const float4 q4 = pts[Q.pts_off + (valid ? s0 + lane : s0)];          // padding lanes shadow the wave's first query
+    const float qx = q4.x, qy = q4.y, qz = q4.z;
+    const int nrow = (depth - 1) / 7 * 8;                    // one 8-row frame of per-lane bounds per level 2..K
+    float* s_w = s_pk + (size_t)wib * (256 * CH_LEAF_LDS + nrow * 64 + depth);
+    float4* s_pt = reinterpret_cast<float4*>(s_w);
+    float* s_lb = s_w + 256 * CH_LEAF_LDS;
+    int* s_nd = reinterpret_cast<int*>(s_lb + (size_t)nrow * 64);
+    const float4* __restrict__ tp = pts + T.pts_off;
+    // (distance bits << 32 | index): distances are >= +0, so unsigned order = (distance, index) lexicographic order
+    unsigned long long bk = ((unsigned long long)__float_as_uint(CH_BIG) << 32) | 0x7fffffffu;
+    int sp = 0;
+    int cur = T.K << 28;
+    for (;;) {
+        const int k = cur >> 28, j = cur & 0x0fffffff;
+        const float* __restrict__ blk = boxes + (size_t)(T.blk_off[k] + j) * 48;
+        float4 mine;
+#if CH_LEAF_LDS
+        if (k == 1) mine = tp[(size_t)j * 64 + lane];        // the block's 64 points, one coalesced KB, in flight with the boxes
+#endif
+        const float best = __uint_as_float((unsigned)(bk >> 32));
+        float lb[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float gx = fmaxf(fmaxf(blk[c] - qx, qx - blk[24 + c]), 0.f);
+            const float gy = fmaxf(fmaxf(blk[8 + c] - qy, qy - blk[32 + c]), 0.f);
+            const float gz = fmaxf(fmaxf(blk[16 + c] - qz, qz - blk[40 + c]), 0.f);
+            lb[c] = ch_d2(gx, gy, gz);
+        }
+        bool have = false;
+        if (k == 1) {
+#if CH_LEAF_LDS
+            s_pt[lane] = mine;
+#endif
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (__ballot(lb[c] <= __uint_as_float((unsigned)(bk >> 32))) == 0) continue;
+#if !CH_LEAF_LDS
+                const float4* __restrict__ pp = tp + (size_t)(8 * j + c) * 8;
+#endif
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+#if CH_LEAF_LDS
+                    const float4 v = s_pt[8 * c + e];        // uniform address: LDS broadcast
+#else
+                    const float4 v = pp[e];                  // uniform address: scalar load
+#endif
+                    const float d = ch_d2(v.x - qx, v.y - qy, v.z - qz);
+#if CH_KEY64
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(v.w);
+                    bk = key < bk ? key : bk;
+#else
+                    const float b0 = __uint_as_float((unsigned)(bk >> 32)); const int id = __float_as_int(v.w);
+                    if (d < b0 || (d == b0 && id < (int)(unsigned)bk)) bk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+#endif
+                }
+            }
+        } else {
+            // Postpone the wanted children far -> near as the MIDDLE query sees them (so the nearest is popped first).
+            // Their per-lane bounds go to this level's frame (8 rows); an entry finds its row from its own level and
+            // child slot, and a level's frame is dead before another node of that level is visited (DFS).
+            float* fr = s_lb + (size_t)(k - 2) * 512;
+            unsigned key[8]; unsigned W = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                fr[c * 64 + lane] = lb[c];
+                if (__ballot(lb[c] <= best) != 0) W |= 1u << c;
+                key[c] = ((unsigned)__builtin_amdgcn_readlane(__float_as_int(lb[c]), 32) & ~7u) | (unsigned)c;
+            }
+#define CH_CX(a, b) { const unsigned lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = hi_; key[b] = lo_; }
+            CH_CX(0, 1) CH_CX(2, 3) CH_CX(4, 5) CH_CX(6, 7)
+            CH_CX(0, 2) CH_CX(1, 3) CH_CX(4, 6) CH_CX(5, 7)
+            CH_CX(1, 2) CH_CX(5, 6) CH_CX(0, 4) CH_CX(3, 7)
+            CH_CX(1, 5) CH_CX(2, 6)
+            CH_CX(1, 4) CH_CX(3, 6)
+            CH_CX(2, 4) CH_CX(3, 5)
+            CH_CX(3, 4)
+#undef CH_CX
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int c = key[r] & 7;
+                if ((W >> c) & 1) { s_nd[sp] = ((k - 1) << 28) | (8 * j + c); sp++; }
+            }
+        }
+        while (!have && sp > 0) {
+            sp--;
+            const int e = __builtin_amdgcn_readfirstlane(s_nd[sp]);
+            const float l = s_lb[(size_t)(((e >> 28) - 1) * 8 + (e & 7)) * 64 + lane];
+            if (__ballot(l <= __uint_as_float((unsigned)(bk >> 32))) != 0) { cur = e; have = true; }
+        }
+        if (!have) break;
+    }
+    float best = __uint_as_float((unsigned)(bk >> 32)); int besti = (int)(unsigned)bk;
+    if (besti == 0x7fffffff) {                              // non-finite input: the reference keeps candidate 0 (`k==0 ||`)
+        const float* c0 = p.xyz[1 - dir];
+        best = ch_d2(c0[0] - qx, c0[1] - qy, c0[2] - qz); besti = 0;
+    }
+    if (valid) {
+        const int qi = __float_as_int(q4.w);
+        p.dist[dir][qi] = best;
+        p.idx[dir][qi] = besti;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -397,7 +539,7 @@ static int ch_ensure(lrt_chamfer* ch, size_t n_total, size_t n_best, hipStream_t
     CH_HIPCHK(hipMalloc(&ch->keys_a, cap * 4)); CH_HIPCHK(hipMalloc(&ch->keys_b, cap * 4));
     CH_HIPCHK(hipMalloc(&ch->vals_a, cap * 4)); CH_HIPCHK(hipMalloc(&ch->vals_b, cap * 4));
     size_t tmp = 0;
-    CH_HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, cap, 0, 31, stream));
+    CH_HIPCHK(rocprim::radix_sort_pairs<ch_sort_cfg>(nullptr, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, cap, 0, 31, stream));
     ch->sort_tmp_bytes = tmp + 256;
     CH_HIPCHK(hipMalloc(&ch->sort_tmp, ch->sort_tmp_bytes));
     CH_HIPCHK(hipMalloc(&ch->pts, (cap + 256) * sizeof(float4)));
@@ -448,12 +590,12 @@ static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, cons
     hipLaunchKernelGGL(kc_bounds, dim3(bb), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds);
     hipLaunchKernelGGL(kc_keys, dim3((n + 255) / 256), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds, ch->keys_a, ch->vals_a);
     size_t tmp = ch->sort_tmp_bytes;
-    CH_HIPCHK(rocprim::radix_sort_pairs(ch->sort_tmp, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, (size_t)n, 0, 31, stream));
+    CH_HIPCHK(rocprim::radix_sort_pairs<ch_sort_cfg>(ch->sort_tmp, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, (size_t)n, 0, 31, stream));
     hipLaunchKernelGGL(kc_leaves, dim3((total_pts + 255) / 256), dim3(256), 0, stream, p, ch->vals_b);
     const int Kmax = p.t[0].K > p.t[1].K ? p.t[0].K : p.t[1].K;
     for (int k = 2; k <= Kmax; k++) {
         const int c0 = k <= p.t[0].K ? ((p.t[0].n_lvl[k] + 7) / 8) * 8 : 0, c1 = k <= p.t[1].K ? ((p.t[1].n_lvl[k] + 7) / 8) * 8 : 0;
-        if ((c0 > c1 ? c0 : c1) > 4096) {
+        if ((c0 > c1 ? c0 : c1) > CH_TOP_MAX) {
             hipLaunchKernelGGL(kc_level, dim3((c0 + c1 + 255) / 256), dim3(256), 0, stream, p, k, c0);
         } else {
             hipLaunchKernelGGL(kc_top, dim3(2), dim3(1024), 0, stream, p, k);
@@ -461,11 +603,18 @@ static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, cons
         }
     }
     const int depth = 7 * (Kmax - 1) + 1;
-    const size_t lds = (size_t)depth * CH_QBLOCK * sizeof(unsigned long long);
-    if (lds > 160 * 1024) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_forward: clouds too large for the LDS stack");
-    if (lds > 64 * 1024)
-        CH_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kc_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kc_query, dim3((n + CH_QBLOCK - 1) / CH_QBLOCK), dim3(CH_QBLOCK), lds, stream, p, depth);
+    if (ch->mode == 3) {                                    // lane-per-query kernel (kept for A/B measurements)
+        const size_t lds = (size_t)depth * CH_QBLOCK * sizeof(unsigned long long);
+        if (lds > 160 * 1024) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_forward: clouds too large for the LDS stack");
+        if (lds > 64 * 1024)
+            CH_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kc_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kc_query, dim3((n + CH_QBLOCK - 1) / CH_QBLOCK), dim3(CH_QBLOCK), lds, stream, p, depth);
+    } else {
+        const size_t lds = (size_t)CH_PK_WAVES * (256 * CH_LEAF_LDS + (Kmax - 1) * 8 * 64 + depth) * sizeof(float);
+        const int waves = total_pts / 64;
+        hipLaunchKernelGGL(kc_query_pk, dim3((waves + CH_PK_WAVES - 1) / CH_PK_WAVES), dim3(64 * CH_PK_WAVES), lds, stream, p,
+                           (const float*)ch->boxes, (const float4*)ch->pts, depth);
+    }
     CH_HIPCHK(hipGetLastError());
     return LRT_OK;
 }
@@ -503,7 +652,7 @@ void lrt_chamfer_destroy(lrt_chamfer* ch)
 int lrt_chamfer_set_option(lrt_chamfer* ch, const char* name, int value)
 {
     if (!ch || !name) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_set_option: null argument");
-    if (!strcmp(name, "mode")) { if (value < 0 || value > 2) CH_FAIL(LRT_ERR_ARG, "mode must be 0, 1 or 2"); ch->mode = value; return LRT_OK; }
+    if (!strcmp(name, "mode")) { if (value < 0 || value > 3) CH_FAIL(LRT_ERR_ARG, "mode must be 0..3"); ch->mode = value; return LRT_OK; }
     if (!strcmp(name, "brute_max_pairs_log2")) { if (value < 0 || value > 62) CH_FAIL(LRT_ERR_ARG, "brute_max_pairs_log2 out of range"); ch->brute_max_pairs_log2 = value; return LRT_OK; }
     CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_set_option: unknown option '%s'", name);
 }

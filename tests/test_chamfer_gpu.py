@@ -51,7 +51,7 @@ def rand_clouds(B, N, M, seed, scale=20.0):
     return a, b
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 @pytest.mark.parametrize("B,N,M", [(1, 1, 1), (1, 1, 700), (1, 700, 1), (1, 7, 9), (1, 64, 65), (2, 513, 4097),
                                    (3, 1000, 777), (1, 20000, 15000)])
 def test_forward_bit_exact_random(B, N, M, mode):
@@ -59,13 +59,13 @@ def test_forward_bit_exact_random(B, N, M, mode):
     assert_bit_exact(run_hip(a, b, mode), och.chamfer_forward(a, b))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_forward_bit_exact_lidar_frame(mode):
     a, b = lidar_clouds(32, 1024, 5)
     assert_bit_exact(run_hip(a, b, mode), och.chamfer_forward(a, b))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_exact_ties_keep_the_first_index(mode):
     r = np.random.default_rng(3)
     b = r.integers(-6, 7, (1, 5000, 3)).astype(np.float32)         # lattice: thousands of exact duplicates and ties
@@ -83,7 +83,8 @@ def test_degenerate_clouds_tree_mode():
     line = np.zeros((1, 400, 3), np.float32); line[0, :, 0] = r.standard_normal(400)
     far = (r.standard_normal((1, 500, 3))).astype(np.float32); far[0, 17] = (1e6, -1e6, 1e6)
     for a, b in ((same, same), (same, line), (line, far), (far, far[:, ::-1].copy())):
-        assert_bit_exact(run_hip(a, b, 1), och.chamfer_forward(a, b))
+        for mode in (1, 3):
+            assert_bit_exact(run_hip(a, b, mode), och.chamfer_forward(a, b))
 
 
 def test_full_frame_tree_equals_brute_force_and_invariants():
