@@ -16,7 +16,9 @@ EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lr
            "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial",
            # include/lrt_chamfer.h
            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
-           "lrt_chamfer_set_option")
+           "lrt_chamfer_set_option",
+           # include/lrt_knn.h
+           "lrt_knn_mean_dist2")
 
 _lib = None
 
@@ -61,6 +63,7 @@ def load():
     lib.lrt_chamfer_backward.restype = ci
     lib.lrt_chamfer_backward.argtypes = [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.lrt_chamfer_set_option.restype = ci; lib.lrt_chamfer_set_option.argtypes = [vp, C.c_char_p, ci]
+    lib.lrt_knn_mean_dist2.restype = ci; lib.lrt_knn_mean_dist2.argtypes = [vp, ci, vp, vp, vp]
     if lib.lrt_abi_version() != 1:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
     _lib = lib

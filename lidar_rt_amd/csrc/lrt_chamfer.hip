@@ -26,6 +26,7 @@
 
 #include "../../include/lrt.h"
 #include "../../include/lrt_chamfer.h"
+#include "../../include/lrt_knn.h"
 
 #ifndef CH_MERGE_LIMIT
 #define CH_MERGE_LIMIT (1024 * 1024)
@@ -290,47 +291,40 @@ __global__ __launch_bounds__(CH_QBLOCK) void kc_query(ChParams p, int depth)
 // the result stays bit-identical.  Per-lane bounds of postponed children sit in an LDS stack ([depth][64] floats +
 // the uniform entry word) so that a popped entry nobody needs any more costs one ds_read + ballot.
 #define CH_PK_WAVES 4
-#ifndef CH_LEAF_LDS
-#define CH_LEAF_LDS 0
-#endif
-#ifndef CH_KEY64
-#define CH_KEY64 1
-#endif
+// KNN3 = false: nearest neighbour in the OTHER cloud (Chamfer).  KNN3 = true: the three smallest squared distances to
+// the OTHER POINTS OF THE SAME cloud (simple-knn's distCUDA2; p.t[0] only, the point's own sorted slot is skipped).
+template <bool KNN3>
 __global__ __launch_bounds__(64 * CH_PK_WAVES) void kc_query_pk(ChParams p, const float* __restrict__ boxes,
                                                                 const float4* __restrict__ pts, int depth)
 {
-    extern __shared__ float s_pk[];                          // per wave: 64 float4 leaf points, depth x 64 bounds, depth entry words
+    extern __shared__ float s_pk[];                          // per wave: (K-1) frames of 8 x 64 bounds, then `depth` entry words
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * CH_PK_WAVES + wib);
-    const int nw0 = p.t[1].pts_off >> 6;                     // waves whose queries are cloud 0's points
-    const int nw1 = (((p.t[1].n_lvl[1] + 7) / 8) * 64) >> 6;
+    const int nw0 = (((p.t[0].n_lvl[1] + 7) / 8) * 64) >> 6; // waves whose queries are cloud 0's points
+    const int nw1 = KNN3 ? 0 : (((p.t[1].n_lvl[1] + 7) / 8) * 64) >> 6;
     if (wave >= nw0 + nw1) return;
     const int dir = wave >= nw0;
     const ChTree& Q = p.t[dir];                              // the queries' own cloud
-    const ChTree& T = p.t[1 - dir];                          // the cloud searched
+    const ChTree& T = p.t[KNN3 ? 0 : 1 - dir];               // the cloud searched
     const int s0 = (wave - (dir ? nw0 : 0)) * 64;
     const bool valid = s0 + lane < Q.n;
     const float4 q4 = pts[Q.pts_off + (valid ? s0 + lane : s0)];          // padding lanes shadow the wave's first query
     const float qx = q4.x, qy = q4.y, qz = q4.z;
+    const int myslot = valid ? s0 + lane : -1;
     const int nrow = (depth - 1) / 7 * 8;                    // one 8-row frame of per-lane bounds per level 2..K
-    float* s_w = s_pk + (size_t)wib * (256 * CH_LEAF_LDS + nrow * 64 + depth);
-    float4* s_pt = reinterpret_cast<float4*>(s_w);
-    float* s_lb = s_w + 256 * CH_LEAF_LDS;
+    float* s_lb = s_pk + (size_t)wib * (nrow * 64 + depth);
     int* s_nd = reinterpret_cast<int*>(s_lb + (size_t)nrow * 64);
     const float4* __restrict__ tp = pts + T.pts_off;
-    // (distance bits << 32 | index): distances are >= +0, so unsigned order = (distance, index) lexicographic order
+    // Chamfer: (distance bits << 32 | index); distances are >= +0, so unsigned order = (distance, index) lexicographic
     unsigned long long bk = ((unsigned long long)__float_as_uint(CH_BIG) << 32) | 0x7fffffffu;
+    float b0 = 3.402823466e38f, b1 = 3.402823466e38f, b2 = 3.402823466e38f;   // KNN3: ascending, FLT_MAX like simple_knn.cu:154
     int sp = 0;
     int cur = T.K << 28;
     for (;;) {
         const int k = cur >> 28, j = cur & 0x0fffffff;
         const float* __restrict__ blk = boxes + (size_t)(T.blk_off[k] + j) * 48;
-        float4 mine;
-#if CH_LEAF_LDS
-        if (k == 1) mine = tp[(size_t)j * 64 + lane];        // the block's 64 points, one coalesced KB, in flight with the boxes
-#endif
-        const float best = __uint_as_float((unsigned)(bk >> 32));
+        const float best = KNN3 ? b2 : __uint_as_float((unsigned)(bk >> 32));
         float lb[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -339,32 +333,24 @@ __global__ __launch_bounds__(64 * CH_PK_WAVES) void kc_query_pk(ChParams p, cons
             const float gz = fmaxf(fmaxf(blk[16 + c] - qz, qz - blk[40 + c]), 0.f);
             lb[c] = ch_d2(gx, gy, gz);
         }
-        bool have = false;
         if (k == 1) {
-#if CH_LEAF_LDS
-            s_pt[lane] = mine;
-#endif
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                if (__ballot(lb[c] <= __uint_as_float((unsigned)(bk >> 32))) == 0) continue;
-#if !CH_LEAF_LDS
+                if (__ballot(lb[c] <= (KNN3 ? b2 : __uint_as_float((unsigned)(bk >> 32)))) == 0) continue;
                 const float4* __restrict__ pp = tp + (size_t)(8 * j + c) * 8;
-#endif
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-#if CH_LEAF_LDS
-                    const float4 v = s_pt[8 * c + e];        // uniform address: LDS broadcast
-#else
                     const float4 v = pp[e];                  // uniform address: scalar load
-#endif
-                    const float d = ch_d2(v.x - qx, v.y - qy, v.z - qz);
-#if CH_KEY64
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(v.w);
-                    bk = key < bk ? key : bk;
-#else
-                    const float b0 = __uint_as_float((unsigned)(bk >> 32)); const int id = __float_as_int(v.w);
-                    if (d < b0 || (d == b0 && id < (int)(unsigned)bk)) bk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
-#endif
+                    float d = ch_d2(v.x - qx, v.y - qy, v.z - qz);
+                    if (KNN3) {
+                        if ((8 * j + c) * 8 + e == myslot) d = __uint_as_float(0x7f800000u);      // `if (i == idx) continue;`
+                        float t = fminf(b0, d); d = fmaxf(b0, d); b0 = t;                        // updateKBest<3>, simple_knn.cu:129-143
+                        t = fminf(b1, d); d = fmaxf(b1, d); b1 = t;
+                        b2 = fminf(b2, d);
+                    } else {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(v.w);
+                        bk = key < bk ? key : bk;
+                    }
                 }
             }
         } else {
@@ -394,24 +380,28 @@ __global__ __launch_bounds__(64 * CH_PK_WAVES) void kc_query_pk(ChParams p, cons
                 if ((W >> c) & 1) { s_nd[sp] = ((k - 1) << 28) | (8 * j + c); sp++; }
             }
         }
+        bool have = false;
         while (!have && sp > 0) {
             sp--;
             const int e = __builtin_amdgcn_readfirstlane(s_nd[sp]);
             const float l = s_lb[(size_t)(((e >> 28) - 1) * 8 + (e & 7)) * 64 + lane];
-            if (__ballot(l <= __uint_as_float((unsigned)(bk >> 32))) != 0) { cur = e; have = true; }
+            if (__ballot(l <= (KNN3 ? b2 : __uint_as_float((unsigned)(bk >> 32)))) != 0) { cur = e; have = true; }
         }
         if (!have) break;
+    }
+    if (!valid) return;
+    const int qi = __float_as_int(q4.w);
+    if (KNN3) {
+        p.dist[0][qi] = (b0 + b1 + b2) / 3.0f;              // simple_knn.cu:183
+        return;
     }
     float best = __uint_as_float((unsigned)(bk >> 32)); int besti = (int)(unsigned)bk;
     if (besti == 0x7fffffff) {                              // non-finite input: the reference keeps candidate 0 (`k==0 ||`)
         const float* c0 = p.xyz[1 - dir];
         best = ch_d2(c0[0] - qx, c0[1] - qy, c0[2] - qz); besti = 0;
     }
-    if (valid) {
-        const int qi = __float_as_int(q4.w);
-        p.dist[dir][qi] = best;
-        p.idx[dir][qi] = besti;
-    }
+    p.dist[dir][qi] = best;
+    p.idx[dir][qi] = besti;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -549,6 +539,57 @@ static int ch_ensure(lrt_chamfer* ch, size_t n_total, size_t n_best, hipStream_t
     return LRT_OK;
 }
 
+// Sort the cloud(s) (M may be 0: a single cloud), gather the sorted points and build the box levels.
+static int ch_build_trees(lrt_chamfer* ch, ChParams& p, int N, const float* xyz1, int M, const float* xyz2,
+                          hipStream_t stream, int* Kmax_out, int* total_pts_out)
+{
+    memset(&p, 0, sizeof(p));
+    int blk = 0;
+    ch_layout(N, 0, &blk, &p.t[0]);
+    if (M > 0) ch_layout(M, ch_pad64(p.t[0]), &blk, &p.t[1]);
+    else p.t[1].pts_off = ch_pad64(p.t[0]);                 // empty second cloud: K = 0, no boxes, no points
+    const int total_pts = ch_pad64(p.t[0]) + (M > 0 ? ch_pad64(p.t[1]) : 0);
+    if ((size_t)total_pts > ch->cap + 256 || (size_t)blk > ch->cap_blocks)
+        CH_FAIL(LRT_ERR_STATE, "lrt_chamfer: workspace layout exceeds capacity (%d pts, %d blocks)", total_pts, blk);
+    p.n[0] = N; p.n[1] = M; p.xyz[0] = xyz1; p.xyz[1] = xyz2;
+    p.pts = ch->pts; p.boxes = ch->boxes;
+    const int n = N + M;
+    hipLaunchKernelGGL(kc_init, dim3(1), dim3(64), 0, stream, ch->bounds);
+    int bb = (n + 1023) / 1024; if (bb > 512) bb = 512;
+    hipLaunchKernelGGL(kc_bounds, dim3(bb), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds);
+    hipLaunchKernelGGL(kc_keys, dim3((n + 255) / 256), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds, ch->keys_a, ch->vals_a);
+    size_t tmp = ch->sort_tmp_bytes;
+    CH_HIPCHK(rocprim::radix_sort_pairs<ch_sort_cfg>(ch->sort_tmp, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, (size_t)n, 0, 31, stream));
+    hipLaunchKernelGGL(kc_leaves, dim3((total_pts + 255) / 256), dim3(256), 0, stream, p, ch->vals_b);
+    const int Kmax = p.t[0].K > p.t[1].K ? p.t[0].K : p.t[1].K;
+    for (int k = 2; k <= Kmax; k++) {
+        const int c0 = k <= p.t[0].K ? ((p.t[0].n_lvl[k] + 7) / 8) * 8 : 0, c1 = k <= p.t[1].K ? ((p.t[1].n_lvl[k] + 7) / 8) * 8 : 0;
+        if ((c0 > c1 ? c0 : c1) > CH_TOP_MAX) {
+            hipLaunchKernelGGL(kc_level, dim3((c0 + c1 + 255) / 256), dim3(256), 0, stream, p, k, c0);
+        } else {
+            hipLaunchKernelGGL(kc_top, dim3(2), dim3(1024), 0, stream, p, k);
+            break;
+        }
+    }
+    *Kmax_out = Kmax; *total_pts_out = total_pts;
+    return LRT_OK;
+}
+
+template <bool KNN3>
+static int ch_launch_pk(lrt_chamfer* ch, const ChParams& p, int Kmax, int total_pts, hipStream_t stream)
+{
+    const int depth = 7 * (Kmax - 1) + 1;
+    const size_t lds = (size_t)CH_PK_WAVES * ((Kmax - 1) * 8 * 64 + depth) * sizeof(float);
+    if (lds > 160 * 1024) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer: cloud too large for the LDS frames");
+    if (lds > 64 * 1024)
+        CH_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kc_query_pk<KNN3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int waves = total_pts / 64;
+    hipLaunchKernelGGL(kc_query_pk<KNN3>, dim3((waves + CH_PK_WAVES - 1) / CH_PK_WAVES), dim3(64 * CH_PK_WAVES), lds, stream, p,
+                       (const float*)ch->boxes, (const float4*)ch->pts, depth);
+    CH_HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
 static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, const float* xyz2, float* dist1, float* dist2,
                           int32_t* idx1, int32_t* idx2, hipStream_t stream)
 {
@@ -575,33 +616,11 @@ static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, cons
         CH_HIPCHK(hipGetLastError());
         return LRT_OK;
     }
-    ChParams p; memset(&p, 0, sizeof(p));
-    int blk = 0;
-    ch_layout(N, 0, &blk, &p.t[0]);
-    ch_layout(M, ch_pad64(p.t[0]), &blk, &p.t[1]);
-    const int total_pts = ch_pad64(p.t[0]) + ch_pad64(p.t[1]);
-    if ((size_t)total_pts > ch->cap + 256 || (size_t)blk > ch->cap_blocks)
-        CH_FAIL(LRT_ERR_STATE, "lrt_chamfer_forward: workspace layout exceeds capacity (%d pts, %d blocks)", total_pts, blk);
-    p.n[0] = N; p.n[1] = M; p.xyz[0] = xyz1; p.xyz[1] = xyz2; p.dist[0] = dist1; p.dist[1] = dist2; p.idx[0] = idx1; p.idx[1] = idx2;
-    p.pts = ch->pts; p.boxes = ch->boxes;
+    ChParams p; int Kmax = 0, total_pts = 0;
+    rc = ch_build_trees(ch, p, N, xyz1, M, xyz2, stream, &Kmax, &total_pts);
+    if (rc != LRT_OK) return rc;
+    p.dist[0] = dist1; p.dist[1] = dist2; p.idx[0] = idx1; p.idx[1] = idx2;
     const int n = N + M;
-    hipLaunchKernelGGL(kc_init, dim3(1), dim3(64), 0, stream, ch->bounds);
-    int bb = (n + 1023) / 1024; if (bb > 512) bb = 512;
-    hipLaunchKernelGGL(kc_bounds, dim3(bb), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds);
-    hipLaunchKernelGGL(kc_keys, dim3((n + 255) / 256), dim3(256), 0, stream, N, xyz1, M, xyz2, ch->bounds, ch->keys_a, ch->vals_a);
-    size_t tmp = ch->sort_tmp_bytes;
-    CH_HIPCHK(rocprim::radix_sort_pairs<ch_sort_cfg>(ch->sort_tmp, tmp, ch->keys_a, ch->keys_b, ch->vals_a, ch->vals_b, (size_t)n, 0, 31, stream));
-    hipLaunchKernelGGL(kc_leaves, dim3((total_pts + 255) / 256), dim3(256), 0, stream, p, ch->vals_b);
-    const int Kmax = p.t[0].K > p.t[1].K ? p.t[0].K : p.t[1].K;
-    for (int k = 2; k <= Kmax; k++) {
-        const int c0 = k <= p.t[0].K ? ((p.t[0].n_lvl[k] + 7) / 8) * 8 : 0, c1 = k <= p.t[1].K ? ((p.t[1].n_lvl[k] + 7) / 8) * 8 : 0;
-        if ((c0 > c1 ? c0 : c1) > CH_TOP_MAX) {
-            hipLaunchKernelGGL(kc_level, dim3((c0 + c1 + 255) / 256), dim3(256), 0, stream, p, k, c0);
-        } else {
-            hipLaunchKernelGGL(kc_top, dim3(2), dim3(1024), 0, stream, p, k);
-            break;
-        }
-    }
     const int depth = 7 * (Kmax - 1) + 1;
     if (ch->mode == 3) {                                    // lane-per-query kernel (kept for A/B measurements)
         const size_t lds = (size_t)depth * CH_QBLOCK * sizeof(unsigned long long);
@@ -610,10 +629,8 @@ static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, cons
             CH_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kc_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc_query, dim3((n + CH_QBLOCK - 1) / CH_QBLOCK), dim3(CH_QBLOCK), lds, stream, p, depth);
     } else {
-        const size_t lds = (size_t)CH_PK_WAVES * (256 * CH_LEAF_LDS + (Kmax - 1) * 8 * 64 + depth) * sizeof(float);
-        const int waves = total_pts / 64;
-        hipLaunchKernelGGL(kc_query_pk, dim3((waves + CH_PK_WAVES - 1) / CH_PK_WAVES), dim3(64 * CH_PK_WAVES), lds, stream, p,
-                           (const float*)ch->boxes, (const float4*)ch->pts, depth);
+        rc = ch_launch_pk<false>(ch, p, Kmax, total_pts, stream);
+        if (rc != LRT_OK) return rc;
     }
     CH_HIPCHK(hipGetLastError());
     return LRT_OK;
@@ -672,6 +689,23 @@ int lrt_chamfer_forward(lrt_chamfer* ch, int B, int N, const float* xyz1, int M,
         if (rc != LRT_OK) return rc;
     }
     return LRT_OK;
+}
+
+int lrt_knn_mean_dist2(lrt_chamfer* ch, int P, const float* points, float* mean_dist2, void* stream_)
+{
+    if (!ch) CH_FAIL(LRT_ERR_ARG, "lrt_knn_mean_dist2: null state");
+    if (P < 0 || P > 2000000000) CH_FAIL(LRT_ERR_ARG, "lrt_knn_mean_dist2: bad P %d", P);
+    if (P == 0) return LRT_OK;
+    if (!points || !mean_dist2) CH_FAIL(LRT_ERR_ARG, "lrt_knn_mean_dist2: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    CH_HIPCHK(hipSetDevice(ch->device));
+    int rc = ch_ensure(ch, (size_t)P + 128, 0, stream);
+    if (rc != LRT_OK) return rc;
+    ChParams p; int Kmax = 0, total_pts = 0;
+    rc = ch_build_trees(ch, p, P, points, 0, nullptr, stream, &Kmax, &total_pts);
+    if (rc != LRT_OK) return rc;
+    p.dist[0] = mean_dist2;
+    return ch_launch_pk<true>(ch, p, Kmax, total_pts, stream);
 }
 
 int lrt_chamfer_backward(lrt_chamfer* ch, int B, int N, const float* xyz1, int M, const float* xyz2,

@@ -36,3 +36,11 @@ def chamfer_backward(xyz1, xyz2, graddist1, graddist2, idx1, idx2, prec: str = "
     getattr(lib(), f"orc_chamfer_backward_{prec}")(C.c_int(B), C.c_int(N), _p(a), C.c_int(M), _p(b), _p(g1), _p(g2),
                                                    _p(i1), _p(i2), _p(ga), _p(gb))
     return ga, gb
+
+
+def knn_mean_dist2(points):
+    """simple-knn `distCUDA2`: points (P,3) float32 -> (P,) mean squared distance to the 3 nearest other points."""
+    a = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    out = np.zeros(a.shape[0], np.float32)
+    lib().orc_knn_mean_dist2(C.c_int(a.shape[0]), _p(a), _p(out))
+    return out

@@ -91,3 +91,32 @@ void orc_chamfer_backward_f64(int B, int N, const float* xyz1, int M, const floa
         grad_dir_f64(M, c, a, gd2 + (size_t)b * M, idx2 + (size_t)b * M, g2 + (size_t)b * M * 3, g1 + (size_t)b * N * 3);
     }
 }
+
+/*
+ * orc_knn_mean_dist2 -- restatement of the reference's simple-knn (`distCUDA2`):
+ *   submodules/simple-knn/simple_knn.cu:148-184 boxMeanDist: per point, the three smallest squared distances to the
+ *   other points (`if (i == idx) continue;` skips the point itself by position, :170-171), kept ascending from
+ *   FLT_MAX by updateKBest<3> (:127-144), result (best[0]+best[1]+best[2])/3.0f (:183).
+ *   The reference restricts the scan to 1024-point Morton boxes whose box distance is within the 3rd-neighbour bound
+ *   found among the +-3 Morton neighbours (:157-177); that pruning never discards one of the true three nearest, so
+ *   the full scan below returns the same three distances (a set: independent of scan order).
+ *   Pair distance :131-133 under nvcc contraction = fmaf(dz,dz, fmaf(dy,dy, dx*dx)).
+ * PARITY PINNING: "parity unpinned" against the CUDA binary (no upstream test / fixture); pinned against the float64
+ * definition in tests/test_knn.py.
+ */
+#include <float.h>
+void orc_knn_mean_dist2(int P, const float* pts, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+        float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+        for (int k = 0; k < P; k++) {
+            if (k == i) continue;
+            float dist = d2_v0(pts[3 * (size_t)k] - x, pts[3 * (size_t)k + 1] - y, pts[3 * (size_t)k + 2] - z);
+            for (int j = 0; j < 3; j++)
+                if (best[j] > dist) { float t = best[j]; best[j] = dist; dist = t; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+}

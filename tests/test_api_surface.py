@@ -19,7 +19,7 @@ def lib():
 
 def test_library_exports_every_symbol_the_header_declares(lib):
     names = set()
-    for h in ("lrt.h", "lrt_chamfer.h"):
+    for h in ("lrt.h", "lrt_chamfer.h", "lrt_knn.h"):
         hdr = open(os.path.join(REPO, "include", h)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
         names |= set(re.findall(r"\b(lrt_[a-z_0-9]+)\s*\(", hdr))
@@ -77,7 +77,8 @@ def test_no_cpu_fallback():
     src = "".join(open(os.path.join(os.path.dirname(lidar_rt_amd.__file__), f)).read()
                   for f in ("_capi.py", "parallel.py", "renderer.py", os.path.join("diff_lidar_tracer", "_C.py"),
                             os.path.join("diff_lidar_tracer", "__init__.py"), os.path.join("chamfer3D", "_C.py"),
-                            os.path.join("chamfer3D", "dist_chamfer_3D.py"), os.path.join("chamfer3D", "__init__.py")))
+                            os.path.join("chamfer3D", "dist_chamfer_3D.py"), os.path.join("chamfer3D", "__init__.py"),
+                            os.path.join("simple_knn", "_C.py")))
     assert "oracle" not in src.replace("oracle-backed", "")         # product code never imports the checker
 
 
@@ -100,4 +101,15 @@ def test_chamfer_surface_matches_reference(lib):
         assert not lib.lrt_chamfer_create(0)
         assert b"no HIP device" in lib.lrt_last_error()
     assert lib.lrt_chamfer_forward(None, 1, 1, None, 1, None, None, None, None, None, None) != 0
+    assert b"null state" in lib.lrt_last_error()
+
+
+def test_simple_knn_surface_matches_reference(lib):
+    """lib/scene/gaussian_model.py:16 `from simple_knn._C import distCUDA2` (submodules/simple-knn/ext.cpp:15-17)."""
+    import inspect
+    from simple_knn._C import distCUDA2
+    assert list(inspect.signature(distCUDA2).parameters) == ["points"]
+    with pytest.raises(RuntimeError, match="HIP|cuda"):            # no CPU path
+        distCUDA2(torch.zeros(5, 3))
+    assert lib.lrt_knn_mean_dist2(None, 4, None, None, None) != 0
     assert b"null state" in lib.lrt_last_error()
