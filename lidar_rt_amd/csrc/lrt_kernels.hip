@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <cstring>
 
 #include <vector>
@@ -62,12 +63,14 @@ struct lrt_state {
     float* dbg; size_t dbg_floats;
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
+    unsigned* ctrl;      // 16 words zeroed by ONE memset per forward: [0..7] tile queues, [8] hit_ovf, [9] hit_count, [10] err_flag, [11] ovf_count
+    float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float* hit_w; int defer_colour;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -233,6 +236,7 @@ struct TraceParams {
     float4* ray_pk;        // per ray 4 x float4: (o, dL3) (d, -) (dL0..2, -) (dL5..7, -)
     // collect & resolve forward
     float slab0; int* err_flag; float* cr_lists;
+    float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
 };
 
 
@@ -881,6 +885,7 @@ __global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const flo
 }
 
 #include "lrt_collect.inc"
+#include "lrt_collect4.inc"
 
 __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 {
@@ -977,16 +982,17 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 1; st->defer_colour = 0; st->tile16_w_log2 = 2; st->slab0 = 16.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
-    if (hipMalloc(&st->err_flag, sizeof(int)) != hipSuccess || hipMemset(st->err_flag, 0, sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&st->hit_ovf, sizeof(int)) != hipSuccess || hipMalloc(&st->hit_count, sizeof(unsigned)) != hipSuccess) {
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
         delete st->timers; delete st;
         return nullptr;
     }
-    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0; st->hit_ovf_host[2] = 0;
-    if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess || hipMalloc(&st->tile_counter, 64) != hipSuccess ||
+    st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9;
+    st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
+    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0; st->hit_ovf_host[2] = 0; st->hit_ovf_host[3] = 0;
+    if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hipMalloc failed");
@@ -1000,12 +1006,12 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->tile_counter, st->stats};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->ctrl, st->stats, st->ovf_list};
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n); (void)hipFree(st->hit_ovf);
-    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_count); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_w); (void)hipFree(st->err_flag); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
+    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_w); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1027,7 +1033,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->hit_cap = value; st->hits_valid = 0; return LRT_OK;
     }
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
-    if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 or 1"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
         int l2 = -1;
         for (int i = 0; i <= 4; i++) if ((1 << i) == value && value <= CR_RAYS) l2 = i;
@@ -1212,8 +1219,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
     st->hits_valid = 0;
     st->fwd_serial++;
+    HIPCHK(hipMemsetAsync(st->ctrl, 0, 16 * sizeof(unsigned), stream));      // tile queues, overflow flags and counters: one fill
     const size_t HW = (size_t)H * W;
-    const bool defer = st->fwd_mode == 1 && st->defer_colour;                 // the colour pass reads the hit record
+    const bool defer = (st->fwd_mode == 1 || st->fwd_mode == 2) && st->defer_colour;                 // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
@@ -1243,38 +1251,52 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             st->key_cap = (unsigned)(kc < 0xffffffffull ? kc : 0xffffffffull);
             st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap;
         }
-        HIPCHK(hipMemsetAsync(st->hit_ovf, 0, sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(st->hit_count, 0, sizeof(unsigned), stream));
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_w = st->hit_w;
         tp.hit_count = st->hit_count;
+        if (defer && !st->ovf_list) HIPCHK(hipMalloc(&st->ovf_list, (size_t)st->ovf_cap * sizeof(float4)));
+        tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
     }
-    HIPCHK(hipMemsetAsync(st->err_flag, 0, sizeof(int), stream));
-    if (st->fwd_mode == 1) {
-        const int TW = 1 << st->tile16_w_log2, TH = CR_RAYS / TW;
+    if (st->fwd_mode == 1 || st->fwd_mode == 2) {
+        const bool wg4 = st->fwd_mode == 2;                          // one workgroup of 4 waves per 16-ray tile (k_fwd_cr4)
+        const int tile_rays = wg4 ? C4_RAYS : CR_RAYS;
+        const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
         tp.tw_log2 = st->tile16_w_log2;
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
         tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
         tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag;
         tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
-            HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
-            int blocks = tp.n_tiles < 256 * 16 ? tp.n_tiles : 256 * 16;          // persistent single-wave workgroups (4 per SIMD)
+            // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)
+            const int max_blocks = wg4 ? 256 * st->wg4_per_cu : 256 * 16;
+            int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;
             if (blocks > st->cr_blocks_cap) {
                 HIPCHK(hipStreamSynchronize(stream));
                 (void)hipFree(st->cr_lists); st->cr_lists = nullptr; st->cr_blocks_cap = 0;
                 const int cap = blocks < 256 ? 256 : 256 * 16;
-                HIPCHK(hipMalloc(&st->cr_lists, (size_t)cap * CR_LIST_WORDS * sizeof(float)));
+                const size_t words = CR_LIST_WORDS > C4_LIST_WORDS ? CR_LIST_WORDS : C4_LIST_WORDS;
+                HIPCHK(hipMalloc(&st->cr_lists, (size_t)cap * words * sizeof(float)));
                 st->cr_blocks_cap = cap;
             }
             tp.cr_lists = st->cr_lists;
+            if (getenv("LRT_DEBUG_OCC")) {
+                int n0 = -1, n1 = -1, n2 = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<false>, 64 * C4_NW, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true>, 64 * C4_NW, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_fwd_cr<true>, 64, 0);
+                fprintf(stderr, "[lrt] occupancy blocks/CU: k_fwd_cr4<false> %d, k_fwd_cr4<true> %d, k_fwd_cr<true> %d; launching %d blocks\n", n0, n1, n2, blocks);
+            }
             ScopedTimer tm(st, 1, stream);
+            const float* rec_ = (const float*)st->rec; const float* naos_ = (const float*)st->nodes_aos;
             if (defer && record) {
-                hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+                if (wg4) hipLaunchKernelGGL(k_fwd_cr4<true>, dim3(blocks), dim3(64 * C4_NW), 0, stream, tp, rec_, naos_);
+                else hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
                 const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
+                hipLaunchKernelGGL(k_fwd_colour_ovf, dim3(256), dim3(256), 0, stream, tp);
             } else {
-                hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos);
+                if (wg4) hipLaunchKernelGGL(k_fwd_cr4<false>, dim3(blocks), dim3(64 * C4_NW), 0, stream, tp, rec_, naos_);
+                else hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
             }
         }
         HIPCHK(hipGetLastError());
@@ -1282,10 +1304,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         rc = launch_trace(st, tp, false, stream);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 2, st->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    // [hit_ovf, hit_count, err_flag, ovf_count] in one 16-byte copy
+    HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->ctrl + 8, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (record) {
-        HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->hit_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(st->hit_ovf_host + 1, st->hit_count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipEventRecord(st->hit_ev, stream));
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
     }
@@ -1320,7 +1341,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list, 2 = BVH stack] (more than 256 candidate quads within 0.1 mm along one ray, or BVH stack overflow); use option fwd_mode=0", st->hit_ovf_host[2]);
+        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list (more than 256 candidate quads within 0.1 mm along one ray), 2 = BVH stack, 4 = colour overflow list (> 2^20 composited hits beyond hit_cap; raise the hit_cap option)]; use option fwd_mode=0", st->hit_ovf_host[2]);
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
         if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;

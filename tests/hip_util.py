@@ -5,6 +5,7 @@ import torch
 from lidar_rt_amd.diff_lidar_tracer import Tracer, TracingSettings
 
 DEV = torch.device("cuda:0")
+DEFAULT_OPTS = {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "hit_cap": 256, "wg4_per_cu": 4}     # the library defaults
 
 
 def settings(bg, deg, mod=1.0):
@@ -18,7 +19,7 @@ def run_hip(sc, o, d, deg, bg, dL=None, opts=None, mod=1.0, tracer=None, trainin
     tr = tracer or Tracer()
     if not training:
         tr.eval()
-    for k, v in (opts or {}).items():
+    for k, v in {**DEFAULT_OPTS, **(opts or {})}.items():       # the state is per device: reset what an earlier test set
         tr.optix_context.set_option(k, v)
     t = {k: torch.as_tensor(np.asarray(v, np.float32), device=DEV).requires_grad_(True) for k, v in sc.items()}
     ro, rd = torch.as_tensor(np.asarray(o, np.float32), device=DEV), torch.as_tensor(np.asarray(d, np.float32), device=DEV)

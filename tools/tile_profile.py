@@ -11,7 +11,10 @@ t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
 ray_o, ray_d = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
 bg = torch.as_tensor(scenes.BG_DEFAULT, device=dev)
 be = HipBackend()
-be.state.set_option("debug_rays", 8192)   # 8192*64 floats >= 4 per tile
+be.state.set_option("debug_rays", 16384)   # >= 8 floats per tile
+for kv in os.environ.get("LRT_OPTS", "").split(","):
+    if kv: be.state.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+NT = 8192 * (2 if "s8" in os.environ.get("LRT_HIP_LIB", "") else 1)
 be.build(t["means"], t["scales"], t["rotations"], t["opacities"])
 for _ in range(2):
     be.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
@@ -19,7 +22,7 @@ be.state.enable_stats(True); be.state.enable_timing(True)
 be.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
 st = be.state.get_stats(dev); tm = be.state.get_timing(dev)
 idx, h = be.state.handle(dev)
-buf = np.empty((2, 16, 512, 4), np.float32)
+buf = np.empty((2, 16 * NT // 8192, 512, 4), np.float32)
 be.state._lib.lrt_debug_read(h, 4, buf.ctypes.data_as(C.c_void_p), buf.nbytes, None)
 print("fwd ms", tm["fwd"], "stats", st)
 buf2 = buf[1]; buf = buf[0]
