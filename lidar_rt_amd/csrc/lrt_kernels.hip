@@ -36,6 +36,17 @@
 // (lo > hi) as the huge box [hi, lo] and would descend into it, a far-away point is never reached (|t| >= 1e30).
 #define LRT_EMPTY 1e30f
 
+#ifndef LRT_SORT_LO_BIT
+#define LRT_SORT_LO_BIT 31
+#endif
+#ifndef LRT_BUILD_MERGE_LIMIT
+#define LRT_BUILD_MERGE_LIMIT 131072     // rocPRIM's merge sort below this many primitives, onesweep radix above
+#endif
+#ifndef LRT_BSORT_LO
+#define LRT_BSORT_LO(id_bits) (id_bits)
+#endif
+using lrt_build_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, LRT_BUILD_MERGE_LIMIT>;
+
 static thread_local char g_err[512] = "";
 #define LRT_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
@@ -933,7 +944,7 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     HIPCHK(hipMalloc(&st->vals_a, cap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&st->vals_b, cap * sizeof(uint32_t)));
     size_t tmp = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, cap, 0, 63, stream));
+    HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(nullptr, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, cap, 0, 63, stream));
     st->sort_tmp_bytes = tmp + 256;
     HIPCHK(hipMalloc(&st->sort_tmp, st->sort_tmp_bytes));
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
@@ -1151,7 +1162,8 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
         hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, st->bounds, st->keys_a, st->vals_a);
         size_t tmp = st->sort_tmp_bytes;
         // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
-        HIPCHK(rocprim::radix_sort_pairs(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 24, 63, stream));
+        // the top 32 bits of the 63-bit code (10-11 bits per axis) order the primitives; four 8-bit onesweep passes
+        HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, LRT_SORT_LO_BIT, 63, stream));
         hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
@@ -1369,7 +1381,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
                     size_t tmpb = st->bsort_tmp_bytes;
-                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, 0, id_bits + gbits, stream));
+                    // only the Gaussian bits are sorted: the sort is stable and the ids ascend in the input, so the order inside a run
+                    // is the same as a full-key sort would give (3 instead of 6 radix passes)
+                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
                     if (st->reduce_mode == 0) {
                         const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
