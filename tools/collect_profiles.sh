@@ -14,6 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $SHORT 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $SHORT > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -o p -- $SHORT > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o p -- $SHORT > /dev/null 2> $OUT/pmc_l2.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_lds -o p -- $SHORT > /dev/null 2> $OUT/pmc_lds.err
 find $OUT -name "*.csv" | head -30
 # keep the merge small: drop the per-dispatch kernel trace of the stats run except the stats files
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
