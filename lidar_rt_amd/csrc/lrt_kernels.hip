@@ -77,7 +77,7 @@ struct lrt_state {
     unsigned* ctrl;      // 16 words zeroed by ONE memset per forward: [0..7] tile queues, [8] hit_ovf, [9] hit_count, [10] err_flag, [11] ovf_count
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
-    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float* hit_w; int defer_colour;
+    unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float2* hit_wa; int defer_colour; int fast_valid;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
@@ -239,7 +239,8 @@ struct TraceParams {
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
-    float* hit_w;          // composite weights of the recorded hits (deferred-colour forward)
+    float2* hit_wa;        // deferred-colour forward: per recorded hit (composite weight, unclamped op*G)
+    int fast_prep;         // backward: hit_wa / hit_pk hold the forward's alpha and colour of every recorded hit
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
     const unsigned long long* sorted_keys; unsigned n_hits;
@@ -426,6 +427,9 @@ __global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
 // of the reference's sequential loop (C, D, N "so far", backward.cu:576-604) are wave prefix sums.  131k independent
 // ray tasks instead of 2k waves each walking 64 rays hit by hit.  Writes (t, dL/dalpha, +-w) per hit, the dense
 // (gidx, id) key list and the per-ray pack.
+// FAST: the deferred-colour forward left (weight, op*G) in hit_wa and k_fwd_colour left the hit's colour in hit_pk, so the
+// per-hit gathers of the Gaussian (40 B) and of its SH table (192 B) are not repeated here.
+template <bool FAST>
 __global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
 {
     const int lane = threadIdx.x;
@@ -443,6 +447,7 @@ __global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
             p.ray_pk[4 * (size_t)r + lane] = v;
         }
         const float dL_dbg = dL[0] * bg0 + dL[1] * bg1 + dL[2] * bg2;
+        const bool need_n = (dL[5] != 0.f) || (dL[6] != 0.f) || (dL[7] != 0.f);
         float b[16];
         lrt_sh_basis(p.deg, d, b);
         const unsigned off = p.hit_off[r];
@@ -453,22 +458,33 @@ __global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
             const size_t id = (size_t)r * p.hit_cap + (live ? j : cb);
             const float t = p.hit_t[id];
             const int g = p.hit_g[id];
-            const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
-            const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
-            const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
-            const float op = p.opac[g];
-            float c0, c1, c2; bool cl0;
-            sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
-            LrtHitGeom hg;
-            lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-            const float ao = op * hg.G;
+            float c0, c1, c2, ao, n0 = 0.f, n1 = 0.f, n2 = 0.f; bool cl0;
+            if (FAST) {
+                const float4 cc = p.hit_pk[id];                      // written by k_fwd_colour, overwritten below by the same lane
+                c0 = cc.x; c1 = cc.y; c2 = cc.z; cl0 = cc.w != 0.f;
+                ao = p.hit_wa[id].y;
+                if (need_n) {                                        // normals only matter for upstream gradients on channels 5..7 (D3)
+                    const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
+                    float R[9];
+                    lrt_quat_to_R(q, R);
+                    n0 = R[2]; n1 = R[5]; n2 = R[8];
+                }
+            } else {
+                const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
+                const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
+                const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
+                sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
+                LrtHitGeom hg;
+                lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+                ao = p.opac[g] * hg.G;
+                n0 = hg.R[2]; n1 = hg.R[5]; n2 = hg.R[8];
+            }
             const float alpha = fminf(LRT_ALPHA_MAX, ao);
             const float incl = wave_incl_prod(live ? (1.f - alpha) : 1.f);
             float excl = __shfl_up(incl, 1);
             if (lane == 0) excl = 1.f;
             const float Tk = T_run * excl;
             const float wgt = live ? alpha * Tk : 0.f;
-            const float n0 = hg.R[2], n1 = hg.R[5], n2 = hg.R[8];
             const float sC0 = rC0 + wave_incl_sum(wgt * c0), sC1 = rC1 + wave_incl_sum(wgt * c1), sC2 = rC2 + wave_incl_sum(wgt * c2);
             const float sD = rD + wave_incl_sum(wgt * t);
             const float sN0 = rN0 + wave_incl_sum(wgt * n0), sN1 = rN1 + wave_incl_sum(wgt * n1), sN2 = rN2 + wave_incl_sum(wgt * n2);
@@ -1022,7 +1038,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_w); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1229,7 +1245,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
-    st->hits_valid = 0;
+    st->hits_valid = 0; st->fast_valid = 0;
     st->fwd_serial++;
     HIPCHK(hipMemsetAsync(st->ctrl, 0, 16 * sizeof(unsigned), stream));      // tile queues, overflow flags and counters: one fill
     const size_t HW = (size_t)H * W;
@@ -1238,15 +1254,15 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
-            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp, st->hit_w};
+            void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp, st->hit_wa};
             for (void* q : olds) (void)hipFree(q);
             st->hit_t = nullptr; st->hit_g = nullptr; st->hit_n = nullptr; st->hit_rays_cap = 0; st->hit_cap_alloc = 0;
-            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0; st->hit_off = nullptr; st->scan_tmp = nullptr; st->hit_w = nullptr;
+            st->hit_keys = st->hit_keys_sorted = nullptr; st->hit_pk = st->ray_pk = nullptr; st->bsort_tmp = nullptr; st->key_cap = 0; st->hit_off = nullptr; st->scan_tmp = nullptr; st->hit_wa = nullptr;
             const size_t nrec = HW * (size_t)st->hit_cap;
             if (nrec >= (1ull << 32)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: H*W*hit_cap exceeds 2^32 (lower the hit_cap option)");
             HIPCHK(hipMalloc(&st->hit_t, nrec * sizeof(float)));
             HIPCHK(hipMalloc(&st->hit_g, nrec * sizeof(int)));
-            HIPCHK(hipMalloc(&st->hit_w, nrec * sizeof(float)));
+            HIPCHK(hipMalloc(&st->hit_wa, nrec * sizeof(float2)));
             HIPCHK(hipMalloc(&st->hit_pk, nrec * sizeof(float4)));
             HIPCHK(hipMalloc(&st->ray_pk, HW * 4 * sizeof(float4)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
@@ -1264,7 +1280,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap;
         }
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
-        tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_w = st->hit_w;
+        tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_wa = st->hit_wa; tp.hit_pk = st->hit_pk;
         tp.hit_count = st->hit_count;
         if (defer && !st->ovf_list) HIPCHK(hipMalloc(&st->ovf_list, (size_t)st->ovf_cap * sizeof(float4)));
         tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
@@ -1321,6 +1337,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (record) {
         HIPCHK(hipEventRecord(st->hit_ev, stream));
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
+        st->fast_valid = (st->hits_valid && defer) ? 1 : 0;          // alpha and colour of every recorded hit are on the device
     }
     return LRT_OK;
 }
@@ -1368,7 +1385,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             } else if (tp.n_tiles > 0) {
                 // (1) per-ray replay -> two scalars per hit, (2) radix sort of the (g, id) keys, (3) segmented reduction
                 ScopedTimer tm(st, 2, stream);
-                tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk;
+                tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk; tp.hit_wa = st->hit_wa;
                 { size_t sb = st->scan_tmp_bytes;
                   HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
                 int id_bits = 1; while ((1ull << id_bits) < (unsigned long long)H * W * (unsigned long long)tp.hit_cap) id_bits++;
@@ -1376,7 +1393,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 {
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
-                    hipLaunchKernelGGL(k_bwd_prep, dim3(blocks), dim3(64), 0, stream, tp);
+                    tp.fast_prep = st->fast_valid;
+                    if (tp.fast_prep) hipLaunchKernelGGL(k_bwd_prep<true>, dim3(blocks), dim3(64), 0, stream, tp);
+                    else hipLaunchKernelGGL(k_bwd_prep<false>, dim3(blocks), dim3(64), 0, stream, tp);
                 }
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
