@@ -1356,11 +1356,16 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
     if (P > 0) {   // trace_surfels.cpp:322-329: gradients start from zero
-        HIPCHK(hipMemsetAsync(d_means, 0, (size_t)P * 3 * sizeof(float), stream));
-        HIPCHK(hipMemsetAsync(d_shs, 0, (size_t)P * M * 3 * sizeof(float), stream));
-        HIPCHK(hipMemsetAsync(d_opac, 0, (size_t)P * sizeof(float), stream));
-        HIPCHK(hipMemsetAsync(d_scales, 0, (size_t)P * 2 * sizeof(float), stream));
-        HIPCHK(hipMemsetAsync(d_rots, 0, (size_t)P * 4 * sizeof(float), stream));
+        // adjacent buffers (the Python binding and the sharded path hand over views of one flat tensor) are filled at once
+        struct Seg { float* p; size_t n; } seg[5] = {{d_means, (size_t)P * 3}, {d_shs, (size_t)P * M * 3}, {d_opac, (size_t)P},
+                                                      {d_scales, (size_t)P * 2}, {d_rots, (size_t)P * 4}};
+        for (int i = 1; i < 5; i++) for (int j = i; j > 0 && seg[j].p < seg[j - 1].p; j--) { Seg t = seg[j]; seg[j] = seg[j - 1]; seg[j - 1] = t; }
+        for (int i = 0; i < 5;) {
+            float* b = seg[i].p; size_t n = seg[i].n; int j = i + 1;
+            while (j < 5 && seg[j].p == b + n) { n += seg[j].n; j++; }
+            if (n) HIPCHK(hipMemsetAsync(b, 0, n * sizeof(float), stream));
+            i = j;
+        }
     }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;

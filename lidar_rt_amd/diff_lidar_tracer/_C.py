@@ -227,8 +227,14 @@ def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, bac
     dL = dL_dout_attr_float32.detach().contiguous().to(torch.float32)
     opts = dict(dtype=torch.float32, device=dev)
     if grads_out is None:
-        d_means = torch.empty((P, 3), **opts); d_shs = torch.empty((P, M, 3), **opts)
-        d_opac = torch.empty((P, 1), **opts); d_scales = torch.empty((P, 2), **opts); d_rot = torch.empty((P, 4), **opts)
+        # one allocation, [means | shs | opacities | scales | rotations]: the library zero-fills adjacent buffers in one launch
+        flat = torch.empty(P * (10 + 3 * M), **opts)
+        o0 = 0
+        d_means = flat[o0:o0 + 3 * P].view(P, 3); o0 += 3 * P
+        d_shs = flat[o0:o0 + 3 * M * P].view(P, M, 3); o0 += 3 * M * P
+        d_opac = flat[o0:o0 + P].view(P, 1); o0 += P
+        d_scales = flat[o0:o0 + 2 * P].view(P, 2); o0 += 2 * P
+        d_rot = flat[o0:o0 + 4 * P].view(P, 4)
     else:
         d_means, d_shs, d_opac = grads_out["means"], grads_out["shs"], grads_out["opacities"]
         d_scales, d_rot = grads_out["scales"], grads_out["rotations"]
