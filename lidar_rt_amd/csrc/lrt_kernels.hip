@@ -81,7 +81,7 @@ struct lrt_state {
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -196,10 +196,8 @@ __global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __res
 }
 
 // Level-l nodes (l >= 2): child c of node j is node 8j+c of level l-1.
-__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* __restrict__ nodes,
-                        float* __restrict__ nodes_aos)
+__device__ __forceinline__ void upper_child(int tid, int n_nodes, int node_off, int n_child, int child_off, float* nodes, float* nodes_aos)
 {
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
     int j = tid >> 3, c = tid & 7;
     if (j >= n_nodes) return;
     int ch = j * 8 + c;
@@ -220,6 +218,12 @@ __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, f
     na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
                   : make_float4(hi[1], hi[2], __int_as_float(child_off + ch), __int_as_float(0));
 }
+
+__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* nodes, float* nodes_aos)
+{
+    upper_child(blockIdx.x * blockDim.x + threadIdx.x, n_nodes, node_off, n_child, child_off, nodes, nodes_aos);
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Trace
@@ -249,6 +253,7 @@ struct TraceParams {
     // collect & resolve forward
     float slab0; int* err_flag; float* cr_lists;
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
+    unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
 };
 
 
@@ -920,6 +925,22 @@ __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
     if (i < n) dst[i] = v;
 }
 
+// The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
+__global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
+                                                  unsigned* __restrict__ ctrl)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i < 16) ctrl[i] = 0u;
+    float4* a4 = reinterpret_cast<float4*>(accum);
+    if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
+        for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = (P & ~3) + i; k < P; k += stride) accum[k] = 0.f;
+    } else {
+        for (int k = i; k < P; k += stride) accum[k] = 0.f;
+    }
+    if (out_i32) for (int k = i; k < n_i32; k += stride) out_i32[k] = -1;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 struct DeviceGuard {
@@ -1009,7 +1030,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 16.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
@@ -1061,6 +1082,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     }
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
         int l2 = -1;
@@ -1186,7 +1208,7 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     int total = tree_layout(P, &nl, &L, cnt, off);
     if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
     hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
-    for (int l = 2; l <= L; l++)
+    for (int l = 2; l <= L; l++)    // one launch per level (a single-block loop over the small top levels measured slower)
         hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
     st->P = P; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
@@ -1239,15 +1261,16 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (P > 0 && (!shs || !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null shs/accum pointer");
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
-    if (P > 0) HIPCHK(hipMemsetAsync(accum, 0, (size_t)P * sizeof(float), stream));
-    if (out_i32 && (size_t)H * W > 0)
-        hipLaunchKernelGGL(k_fill_i32, dim3((H * W + 255) / 256), dim3(256), 0, stream, H * W, -1, out_i32);
+    {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
+        const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
+        int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_fwd_init, dim3(blocks), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl);
+    }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
     st->hits_valid = 0; st->fast_valid = 0;
     st->fwd_serial++;
-    HIPCHK(hipMemsetAsync(st->ctrl, 0, 16 * sizeof(unsigned), stream));      // tile queues, overflow flags and counters: one fill
     const size_t HW = (size_t)H * W;
     const bool defer = (st->fwd_mode == 1 || st->fwd_mode == 2) && st->defer_colour;                 // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
@@ -1292,7 +1315,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.tw_log2 = st->tile16_w_log2;
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
         tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
-        tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag;
+        tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag; tp.c4_qlimit = (unsigned)st->c4_qlimit;
         tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)

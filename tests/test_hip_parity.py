@@ -232,6 +232,17 @@ def test_deferred_colour_beyond_the_hit_record(s10k):
             assert rel_l2(b["grads"][k], a["grads"][k]) < 1e-3, k
 
 
+def test_queue_overflow_falls_back_to_narrower_slabs(s10k):
+    """k_fwd_cr4: a BVH queue that would overflow makes the tile halve its depth slab and collect again; with an
+    artificially small limit this happens on many tiles and the result must not change."""
+    sc, o, d, dL = s10k
+    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 200})
+    assert rel_l2(b["out"], a["out"]) < 1e-6 and frac_outside(b["out"], a["out"], 1e-5) <= 1e-4
+    for k in GRADS:
+        assert rel_l2(b["grads"][k], a["grads"][k]) < 1e-5, k
+
+
 def test_two_forwards_before_backward(s10k):
     """The hit record belongs to the LAST forward; the backward of an earlier forward must notice and re-trace."""
     from lidar_rt_amd.diff_lidar_tracer import Tracer

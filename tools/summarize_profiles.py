@@ -79,13 +79,13 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 
     if fs is not None or ws is not None:
         traffic[k] = {"hbm_bytes_per_launch": corr * 1e6, "fetch_kb": fs, "write_kb": ws, "raw_bytes_per_launch": raw * 1e6}
 
-# labels bench.py uses for the dominant kernel
-fwd = next((v for k, v in traffic.items() if k.startswith("k_fwd_cr")), None)
-if fwd:
-    traffic["k_fwd_cr (collect & resolve forward)"] = fwd
+# labels bench.py uses for the dominant (HIP-event timed) region: sums over the kernels of the region
+fw = [traffic[k] for k in traffic if k.startswith("k_fwd_")]
+if fw:
+    traffic["forward (k_fwd_cr4 + k_fwd_colour)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in fw)}
 bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
 if bw:
-    traffic["backward (k_bwd_replay + radix sort + k_bwd_reduce)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
+    traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce2)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
