@@ -85,6 +85,11 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
  * and, on mismatch, sets option "invalidate_record" so that lrt_backward re-traces instead. */
 long long lrt_forward_serial(lrt_state* st);
 
+/* Overflow status of the most recent lrt_forward (the kernels only raise a device flag; lrt_backward checks it too).
+ * wait != 0: block until that forward has finished; wait == 0: report only if it already has.  Returns LRT_ERR_STATE with
+ * a message when its output is incomplete.  lrt_forward calls this (wait = 0) for the previous call. */
+int lrt_check_forward(lrt_state* st, int wait);
+
 /* Optional instrumentation: when enabled, lrt_forward accumulates
  * stats[0] = candidate hits consumed, stats[1] = composited hits, stats[2] = traversal passes (ray-tile restarts),
  * stats[3] = BVH nodes visited (wave level), stats[4] = leaf primitives tested (wave level)

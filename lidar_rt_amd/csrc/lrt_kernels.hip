@@ -81,7 +81,7 @@ struct lrt_state {
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -1110,6 +1110,21 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
 /* Serial number of the most recent lrt_forward on this state (the hit record belongs to that forward). */
 long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
 
+int lrt_check_forward(lrt_state* st, int wait)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_check_forward: null state");
+    if (!st->fwd_pending) return LRT_OK;
+    if (wait) HIPCHK(hipEventSynchronize(st->hit_ev));
+    else if (hipEventQuery(st->hit_ev) != hipSuccess) return LRT_OK;            // still running: ask again later
+    st->fwd_pending = 0;
+    const int code = st->hit_ovf_host[2];
+    if (code != 0)
+        LRT_FAIL(LRT_ERR_STATE, "the last forward trace reported an internal overflow and its output is incomplete [code %d: 1 = more than 256 "
+                 "candidate quads within 0.1 mm along one ray, 2 = BVH queue/stack, 4 = colour overflow list (raise the hit_cap option)]; "
+                 "use option fwd_mode=0", code);
+    return LRT_OK;
+}
+
 int lrt_enable_timing(lrt_state* st, int enable)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_enable_timing: null state");
@@ -1261,6 +1276,8 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (P > 0 && (!shs || !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null shs/accum pointer");
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
+    rc = lrt_check_forward(st, 0);                                              // a finished earlier forward that overflowed is reported now
+    if (rc) return rc;
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
@@ -1357,8 +1374,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     }
     // [hit_ovf, hit_count, err_flag, ovf_count] in one 16-byte copy
     HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->ctrl + 8, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipEventRecord(st->hit_ev, stream));
+    st->fwd_pending = 1;
     if (record) {
-        HIPCHK(hipEventRecord(st->hit_ev, stream));
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
         st->fast_valid = (st->hits_valid && defer) ? 1 : 0;          // alpha and colour of every recorded hit are on the device
     }

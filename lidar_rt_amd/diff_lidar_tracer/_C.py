@@ -69,6 +69,12 @@ class OptiXStateWrapper:
         for h in self._handles.values():
             _capi.check(self._lib.lrt_set_option(h, name.encode(), int(value)), "lrt_set_option")
 
+    def check(self, device=None, wait: bool = True):
+        """Raise if the most recent forward on `device` reported an internal overflow (waits for it when `wait`)."""
+        for idx, h in self._handles.items():
+            if device is None or idx == (torch.device(device).index or 0):
+                _capi.check(self._lib.lrt_check_forward(h, 1 if wait else 0), "lrt_forward")
+
     def enable_stats(self, enable: bool = True):
         self.stats_enabled = bool(enable)
         for h in self._handles.values():

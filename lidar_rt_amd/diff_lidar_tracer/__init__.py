@@ -42,6 +42,9 @@ class _Tracer(torch.autograd.Function):
             state, training, ray_o, ray_d, vertices, ts.bg, means3D, shs, ts.sh_degree, colors_precomp, opacities,
             scales, ts.scale_modifier, rotations, cov3Ds_precomp, ts.viewmatrix, ts.projmatrix, ts.campos,
             ts.prefiltered, ts.debug)
+        if not training or not torch.is_grad_enabled():
+            # no backward will follow to look at the overflow flag: wait for the trace and fail loudly now
+            state.check(means3D.device, wait=True)
         ctx.tracer_settings = ts
         ctx.state = state
         ctx.forward_serial = getattr(state, "last_serial", None)

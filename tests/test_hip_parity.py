@@ -16,6 +16,7 @@ import torch
 
 from lidar_rt_amd import scenes
 from oracle import oracle
+from lidar_rt_amd.diff_lidar_tracer import Tracer
 
 pytestmark = pytest.mark.gpu
 
@@ -230,6 +231,21 @@ def test_deferred_colour_beyond_the_hit_record(s10k):
         assert rel_l2(b["out"], a["out"]) < 1e-5 and frac_outside(b["out"], a["out"], 1e-4) <= 1e-3
         for k in GRADS:
             assert rel_l2(b["grads"][k], a["grads"][k]) < 1e-3, k
+
+
+def test_unrecoverable_overflow_is_reported_loudly(s10k):
+    """A trace that cannot complete (here: a queue limit no slab width can satisfy) must raise, in eval mode right
+    away (no backward follows) and in training mode at the backward."""
+    from lidar_rt_amd._capi import LrtError
+    sc, o, d, dL = s10k
+    tr = Tracer()
+    with pytest.raises(LrtError, match="internal overflow"):
+        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, opts={"c4_queue_limit": 136}, tracer=tr, training=False)
+    tr.train()
+    with pytest.raises(LrtError, match="internal overflow"):
+        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 136}, tracer=tr)
+    h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, tracer=tr)                 # the state recovers with sane options
+    assert not np.isnan(h["out"]).any()
 
 
 def test_queue_overflow_falls_back_to_narrower_slabs(s10k):
