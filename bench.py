@@ -220,8 +220,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
                        "step": ("LBVH rebuild + " if not args.no_build_in_step else "") + "forward + backward"
-                               + (" + slab all_gather + fused gradient all_reduce (RCCL)" if world > 1 else ""),
-                       "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None},
+                               + (" + slab all_gather + gradient exchange (RCCL: all_gather of the touched Gaussians' rows, or one fused all_reduce)" if world > 1 else ""),
+                       "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
+                       "gradient_exchange": tr.last_exchange},
             "roofline": roof,
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }

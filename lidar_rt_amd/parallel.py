@@ -79,7 +79,15 @@ class HipBackend:
 class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
-    def __init__(self, backend=None, group=None):
+    def __init__(self, backend=None, group=None, exchange: str = "auto"):
+        """exchange: "dense" = one all_reduce of the flat gradient buffer; "sparse" = all_gather of the rows of the
+        Gaussians each rank's rays touched (azimuth sectors touch mostly disjoint Gaussians); "auto" = sparse unless the
+        ranks together touched more than `sparse_max_fraction` of the Gaussians."""
+        if exchange not in ("auto", "dense", "sparse"):
+            raise ValueError("exchange must be 'auto', 'dense' or 'sparse'")
+        self.exchange = exchange
+        self.sparse_max_fraction = 0.6
+        self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | None
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -127,6 +135,55 @@ class ShardedTracer:
             for k in direct:
                 direct[k].copy_(g[k].view_as(direct[k]))
         lay.views["accum"].copy_(self._accum_loc)
+        self.last_exchange = None
         if reduce and self.world > 1:
-            dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.exchange == "dense" or not self._exchange_sparse(lay):
+                dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.last_exchange = "dense"
         return lay.views
+
+    def _exchange_sparse(self, lay: GradLayout) -> bool:
+        """Sum the ranks' partial gradients by exchanging only the rows of touched Gaussians.
+
+        A Gaussian has a non-zero partial gradient on a rank only if one of that rank's rays composited it, and every
+        composited hit adds a weight > 0 to `accum` (forward.cu:268), so `accum > 0` is the exact mask.  Each rank
+        all_gathers (index, 60-float row) of its touched Gaussians (padded to the largest count), clears its buffer and
+        adds the ranks' rows in rank order: indices are unique inside a rank, so every rank ends with bit-identical
+        sums.  Returns False (nothing exchanged) when the dense all_reduce moves fewer bytes."""
+        P, M, world = lay.P, lay.M, self.world
+        fields = [(name, k) for name, k in GradLayout.FIELDS] + [("shs", 3 * M), ("accum", 1)]
+        width = sum(k for _, k in fields)
+        dev = lay.flat.device
+        idx = torch.nonzero(lay.views["accum"] > 0).squeeze(1)
+        n = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
+        counts_t = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts_t, n, group=self.group)
+        counts = [int(c.item()) for c in counts_t]                    # the same list on every rank
+        nmax = max(counts)
+        if self.exchange == "auto" and sum(counts) > self.sparse_max_fraction * P:
+            return False
+        pay = torch.zeros((max(nmax, 1), width), dtype=torch.float32, device=dev)
+        ids = torch.zeros(max(nmax, 1), dtype=torch.int32, device=dev)
+        m = idx.numel()
+        if m:
+            col = 0
+            for name, k in fields:
+                pay[:m, col:col + k] = lay.views[name].reshape(P, k).index_select(0, idx)
+                col += k
+            ids[:m] = idx.to(torch.int32)
+        pays = [torch.empty_like(pay) for _ in range(world)]
+        idss = [torch.empty_like(ids) for _ in range(world)]
+        dist.all_gather(pays, pay, group=self.group)
+        dist.all_gather(idss, ids, group=self.group)
+        lay.flat.zero_()
+        for r in range(world):                                        # fixed order -> identical rounding on every rank
+            c = counts[r]
+            if c == 0:
+                continue
+            ridx = idss[r][:c].long()
+            col = 0
+            for name, k in fields:
+                lay.views[name].view(P, k).index_add_(0, ridx, pays[r][:c, col:col + k])
+                col += k
+        self.last_exchange = "sparse"
+        return True

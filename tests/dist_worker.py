@@ -15,6 +15,7 @@ from tests.oracle_backend import OracleBackend        # noqa: E402
 
 def main():
     out_path = sys.argv[1]
+    exchange = sys.argv[2] if len(sys.argv) > 2 else "auto"
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     sc = scenes.make_scene(1500, seed=4, radius_scale=0.2)
@@ -22,12 +23,13 @@ def main():
     dL = scenes.upstream_grad(6, 45)
     t = {k: torch.from_numpy(v) for k, v in sc.items()}
     bg = torch.tensor([0.0, 0.0, 1.0])
-    tr = ShardedTracer(backend=OracleBackend())
+    tr = ShardedTracer(backend=OracleBackend(), exchange=exchange)
     out, _ = tr.forward(torch.from_numpy(o), torch.from_numpy(d), t["means"], t["scales"], t["rotations"],
                         t["opacities"], t["shs"], 3, bg)
     g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, torch.from_numpy(dL))
     a, b = column_slab(45, rank, world)
     assert tr._slab == (a, b)
+    assert tr.last_exchange == ("dense" if exchange == "dense" else "sparse"), tr.last_exchange
     np.savez(out_path + f".rank{rank}.npz", out=out.numpy(), **{k: v.numpy() for k, v in g.items()})
     dist.barrier()
     dist.destroy_process_group()

@@ -33,8 +33,8 @@ def test_grad_layout_is_one_flat_buffer():
     assert float(lay.flat.sum()) == 10 * 48 * 2.0 + 10 * 3.0
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(tmp_path, world):
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "auto")])
+def test_sharded_equals_single(tmp_path, world, exchange):
     sc = scenes.make_scene(1500, seed=4, radius_scale=0.2)
     o, d = scenes.kitti_rays(6, 45)
     dL = scenes.upstream_grad(6, 45)
@@ -47,10 +47,13 @@ def test_sharded_equals_single(tmp_path, world):
     base = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), os.path.join(REPO, "tests", "dist_worker.py"), base]
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), os.path.join(REPO, "tests", "dist_worker.py"), base, exchange]
     subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=600)
+    res0 = np.load(base + ".rank0.npz")
     for r in range(world):
         res = np.load(base + f".rank{r}.npz")
+        for k in ("means", "scales", "rotations", "opacities", "shs", "accum"):
+            np.testing.assert_array_equal(res[k], res0[k])                                    # replicas stay bit-identical
         np.testing.assert_allclose(res["out"], out1.numpy(), rtol=1e-6, atol=1e-7)          # every rank sees the whole image
         for k in ("means", "scales", "rotations", "opacities", "shs", "accum"):
             ref = g1[k].numpy()
