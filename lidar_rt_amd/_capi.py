@@ -18,7 +18,9 @@ EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lr
            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
            "lrt_chamfer_set_option",
            # include/lrt_knn.h
-           "lrt_knn_mean_dist2")
+           "lrt_knn_mean_dist2",
+           # include/lrt_preprocess.h
+           "lrt_preprocess_forward", "lrt_preprocess_backward")
 
 _lib = None
 
@@ -65,6 +67,8 @@ def load():
     lib.lrt_chamfer_backward.argtypes = [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.lrt_chamfer_set_option.restype = ci; lib.lrt_chamfer_set_option.argtypes = [vp, C.c_char_p, ci]
     lib.lrt_knn_mean_dist2.restype = ci; lib.lrt_knn_mean_dist2.argtypes = [vp, ci, vp, vp, vp]
+    lib.lrt_preprocess_forward.restype = ci; lib.lrt_preprocess_forward.argtypes = [ci, ci, ci] + [vp] * 11
+    lib.lrt_preprocess_backward.restype = ci; lib.lrt_preprocess_backward.argtypes = [ci, ci, ci] + [vp] * 14
     if lib.lrt_abi_version() != 1:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
     _lib = lib

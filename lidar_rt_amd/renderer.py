@@ -29,6 +29,33 @@ def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
                         aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
 
 
+use_fused_preprocess = True   # module switch: False forces the getter chain of the reference (used by the tests)
+
+
+def _fused_inputs(frame, assets, dynamic, decomp):
+    """Raw parameters of GaussianModel-like assets (`_xyz`, `_scaling`, `_rotation`, `_opacity`, `bounding_box.frame`)
+    through lidar_rt_amd.preprocess.fused_activations; None when an asset does not expose them or when the reference
+    would treat its position and its rotation inconsistently (posed means without a composed rotation or vice versa)."""
+    from .preprocess import fused_activations, pack_poses
+    poses, counts = [], []
+    for a, pc in enumerate(assets):
+        if not all(hasattr(pc, n) for n in ("_xyz", "_scaling", "_rotation", "_opacity")):
+            return None
+        bb = getattr(pc, "bounding_box", None)
+        fr = bb.frame[frame] if (bb is not None and frame in bb.frame) else None
+        composed = dynamic and decomp != "background" and (decomp == "object" or a >= 1)
+        if (fr is not None) != composed:
+            return None
+        poses.append(None if fr is None else (fr[0], fr[1]))
+        counts.append(pc._xyz.shape[0])
+    if not dynamic and len(assets) > 1:
+        return None                       # the reference takes rot_in_local[0] only (gaussian_renderer/__init__.py:115)
+    dev = assets[0]._xyz.device
+    seg, tab = pack_poses(poses, counts, dev)
+    cat = (lambda name: torch.cat([getattr(pc, name) for pc in assets], 0)) if len(assets) > 1 else (lambda name: getattr(assets[0], name))
+    return fused_activations(cat("_xyz"), cat("_scaling"), cat("_rotation"), cat("_opacity"), seg, tab)
+
+
 def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifier=1.0, override_color=None,
                decomp=False):
     global tracer_2dgs
@@ -53,21 +80,27 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
     e = torch.empty(0, device=dev)
     settings = TracingSettings(None, None, None, None, background.to(dev, torch.float32), 1.0, e, e,
                                gaussian_assets[0].active_sh_degree, sensor_center.to(dev), False, False)
-    means, opac, scales, shs, obj_rot, rot_local = [], [], [], [], [], []
-    for pc in gaussian_assets:
-        means.append(pc.get_world_xyz(frame)); opac.append(pc.get_opacity); scales.append(pc.get_scaling)
-        r1, r2 = pc.get_rotation(frame)
-        obj_rot.append(r1.expand(r2.shape[0], -1)); rot_local.append(r2)
-        shs.append(pc.get_features)
-    means3D = torch.cat(means, 0); opacity = torch.cat(opac, 0); scales = torch.cat(scales, 0); shs = torch.cat(shs, 0)
     dynamic = bool(getattr(args, "dynamic", False))
-    if decomp == "background" or not dynamic:
-        rotations = rot_local[0]
-    elif decomp == "object":
-        rotations = quaternion_raw_multiply(torch.cat(obj_rot, 0), F.normalize(torch.cat(rot_local, 0), dim=1))
+    fused = _fused_inputs(frame, gaussian_assets, dynamic, decomp) if use_fused_preprocess else None
+    if fused is not None:
+        # one HIP launch for activations + actor transforms + quaternion composition + concatenation (and one for its backward)
+        means3D, scales, rotations, opacity = fused
+        shs = torch.cat([pc.get_features for pc in gaussian_assets], 0)
     else:
-        rot_obj = quaternion_raw_multiply(torch.cat(obj_rot[1:], 0), F.normalize(torch.cat(rot_local[1:], 0), dim=1))
-        rotations = torch.cat([rot_local[0], rot_obj], 0)
+        means, opac, scales, shs, obj_rot, rot_local = [], [], [], [], [], []
+        for pc in gaussian_assets:
+            means.append(pc.get_world_xyz(frame)); opac.append(pc.get_opacity); scales.append(pc.get_scaling)
+            r1, r2 = pc.get_rotation(frame)
+            obj_rot.append(r1.expand(r2.shape[0], -1)); rot_local.append(r2)
+            shs.append(pc.get_features)
+        means3D = torch.cat(means, 0); opacity = torch.cat(opac, 0); scales = torch.cat(scales, 0); shs = torch.cat(shs, 0)
+        if decomp == "background" or not dynamic:
+            rotations = rot_local[0]
+        elif decomp == "object":
+            rotations = quaternion_raw_multiply(torch.cat(obj_rot, 0), F.normalize(torch.cat(rot_local, 0), dim=1))
+        else:
+            rot_obj = quaternion_raw_multiply(torch.cat(obj_rot[1:], 0), F.normalize(torch.cat(rot_local[1:], 0), dim=1))
+            rotations = torch.cat([rot_local[0], rot_obj], 0)
     grads3D = torch.zeros_like(means3D, requires_grad=True)
     try:
         means3D.retain_grad()          # train.py:219 reads means3D.grad

@@ -193,11 +193,68 @@ def gen_oracle_vectors(with_s1m: bool):
         print("s1m: C=%.3f K=%.3f" % (C, K))
 
 
+def gen_preprocess_pins():
+    """tests/golden/preprocess_golden.npz: the parameter pre-processing chain of the reference (activations, actor
+    rigid transform, quaternion composition, concatenation over assets) evaluated with the reference's OWN functions
+    (lib/utils/general_utils.py: build_rotation, quaternion_raw_multiply; the getters of lib/scene/gaussian_model.py:112-148
+    are one-line compositions of torch.exp / torch.sigmoid / F.normalize and are called exactly like there), and torch
+    autograd through them for a random upstream gradient."""
+    torch, gu, shu, pu, ls, mode = _import_reference()
+    import torch.nn.functional as F
+    rng = np.random.default_rng(777)
+    counts = [37, 11, 5, 20]                                  # background + 3 actors
+    P = sum(counts)
+    raw = {"xyz": rng.normal(size=(P, 3)).astype(np.float32) * 5, "log_scales": rng.normal(-2, 0.7, (P, 2)).astype(np.float32),
+           "rot_raw": rng.normal(size=(P, 4)).astype(np.float32) * rng.uniform(0.2, 3, (P, 1)).astype(np.float32),
+           "opacity_logit": rng.normal(0, 2, (P, 1)).astype(np.float32)}
+    poses = np.zeros((len(counts), 8), np.float32); poses[:, 3] = 1
+    for a in range(1, len(counts)):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        poses[a] = np.concatenate([rng.normal(size=3) * 10, q, [1.0]])
+    seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in raw.items()}
+    means, obj_rot, rot_local = [], [], []
+    for a in range(len(counts)):
+        s, e = int(seg[a]), int(seg[a + 1])
+        xyz = t["xyz"][s:e]
+        if poses[a, 7] != 0:                                  # get_world_xyz (gaussian_model.py:129-134)
+            qa = torch.from_numpy(poses[a, 3:7]).reshape(1, 4)
+            R = gu.build_rotation(qa).squeeze(0)
+            means.append(xyz @ R.T + torch.from_numpy(poses[a, 0:3]))
+        else:
+            qa = torch.zeros((1, 4))
+            means.append(xyz)
+        obj_rot.append(qa.expand(e - s, -1))                  # gaussian_renderer/__init__.py:90-92
+        rot_local.append(F.normalize(t["rot_raw"][s:e]))      # rotation_activation (gaussian_model.py:32,127)
+    means3D = torch.cat(means, 0)
+    opacity = torch.sigmoid(t["opacity_logit"]); scales = torch.exp(t["log_scales"])
+    rots_bkgd = rot_local[0]                                  # gaussian_renderer/__init__.py:124-130 (dynamic, no decomp)
+    rl = F.normalize(torch.cat(rot_local[1:], 0), dim=1)
+    rotations = torch.cat([rots_bkgd, gu.quaternion_raw_multiply(None, torch.cat(obj_rot[1:], 0), rl)], 0)
+    up = {k: rng.normal(size=v.shape).astype(np.float32) for k, v in
+          (("means", means3D), ("scales", scales), ("rotations", rotations), ("opacities", opacity))}
+    loss = (means3D * torch.from_numpy(up["means"])).sum() + (scales * torch.from_numpy(up["scales"])).sum() + \
+           (rotations * torch.from_numpy(up["rotations"])).sum() + (opacity * torch.from_numpy(up["opacities"])).sum()
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "preprocess_golden.npz"), seg_start=seg, poses=poses,
+                        **{"in_" + k: v for k, v in raw.items()},
+                        out_means=means3D.detach().numpy(), out_scales=scales.detach().numpy(),
+                        out_rotations=rotations.detach().numpy(), out_opacities=opacity.detach().numpy(),
+                        **{"up_" + k: v for k, v in up.items()},
+                        **{"grad_" + k: t[k].grad.numpy() for k in raw})
+    print("preprocess_golden.npz written")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-preprocess", action="store_true")
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--s1m", action="store_true", help="also compute S1M statistics (needs ~1 min)")
     a = ap.parse_args()
+    if a.only_preprocess:
+        gen_preprocess_pins()
+        sys.exit(0)
     if not a.skip_reference:
         gen_reference_pins()
+        gen_preprocess_pins()
     gen_oracle_vectors(a.s1m)

@@ -19,7 +19,7 @@ def lib():
 
 def test_library_exports_every_symbol_the_header_declares(lib):
     names = set()
-    for h in ("lrt.h", "lrt_chamfer.h", "lrt_knn.h"):
+    for h in ("lrt.h", "lrt_chamfer.h", "lrt_knn.h", "lrt_preprocess.h"):
         hdr = open(os.path.join(REPO, "include", h)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
         names |= set(re.findall(r"\b(lrt_[a-z_0-9]+)\s*\(", hdr))
@@ -78,7 +78,7 @@ def test_no_cpu_fallback():
                   for f in ("_capi.py", "parallel.py", "renderer.py", os.path.join("diff_lidar_tracer", "_C.py"),
                             os.path.join("diff_lidar_tracer", "__init__.py"), os.path.join("chamfer3D", "_C.py"),
                             os.path.join("chamfer3D", "dist_chamfer_3D.py"), os.path.join("chamfer3D", "__init__.py"),
-                            os.path.join("simple_knn", "_C.py")))
+                            os.path.join("simple_knn", "_C.py"), "preprocess.py"))
     assert "oracle" not in src.replace("oracle-backed", "")         # product code never imports the checker
 
 
