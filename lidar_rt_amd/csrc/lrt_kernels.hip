@@ -643,18 +643,28 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
         for (int k = 0; k < 16; k++)
             if (k < nsh) { ash[3 * k] = b[k] * c0; ash[3 * k + 1] = b[k] * c1; ash[3 * k + 2] = b[k] * c2; }
     }
-    // segmented inclusive scan; same[s] = the lane 2^s below belongs to the same run
-    bool same[6];
-#pragma unroll
-    for (int s_ = 0; s_ < 6; s_++) { const int off = 1 << s_; const int gp = __shfl_up(g, off); same[s_] = (lane >= off) && (gp == g); }
-#pragma unroll
-    for (int s_ = 0; s_ < 6; s_++) {
-        const int off = 1 << s_;
-#pragma unroll
-        for (int k = 0; k < 10; k++) acc[k] = seg_step(acc[k], off, same[s_], lane);
-#pragma unroll
-        for (int k = 0; k < 48; k++) if (k < 3 * nsh) ash[k] = seg_step(ash[k], off, same[s_], lane);
+    // Segmented inclusive scan over the runs of equal g, on the DPP network (no LDS crossbar traffic): four row_shr steps
+    // inside the 16-lane rows, then the previous row's last lane (row_bcast:15, rows 1 and 3) and lane 31 (row_bcast:31,
+    // rows 2 and 3) as carries.  The keys are sorted, so "same run" = equal g at both ends; lanes without a source read -2.
+    float mk[6];
+    {
+        const int g1 = __builtin_amdgcn_update_dpp(-2, g, 0x111, 0xf, 0xf, false), g2 = __builtin_amdgcn_update_dpp(-2, g, 0x112, 0xf, 0xf, false);
+        const int g4 = __builtin_amdgcn_update_dpp(-2, g, 0x114, 0xf, 0xf, false), g8 = __builtin_amdgcn_update_dpp(-2, g, 0x118, 0xf, 0xf, false);
+        const int gA = __builtin_amdgcn_update_dpp(-2, g, 0x142, 0xa, 0xf, false), gB = __builtin_amdgcn_update_dpp(-2, g, 0x143, 0xc, 0xf, false);
+        mk[0] = g1 == g ? 1.f : 0.f; mk[1] = g2 == g ? 1.f : 0.f; mk[2] = g4 == g ? 1.f : 0.f; mk[3] = g8 == g ? 1.f : 0.f;
+        mk[4] = gA == g ? 1.f : 0.f; mk[5] = gB == g ? 1.f : 0.f;
     }
+#define SEG_SCAN(x) do { \
+        x = fmaf(dpp_f<0x111, 0xf>(0.f, x), mk[0], x); x = fmaf(dpp_f<0x112, 0xf>(0.f, x), mk[1], x); \
+        x = fmaf(dpp_f<0x114, 0xf>(0.f, x), mk[2], x); x = fmaf(dpp_f<0x118, 0xf>(0.f, x), mk[3], x); \
+        x = fmaf(dpp_f<0x142, 0xa>(0.f, x), mk[4], x); x = fmaf(dpp_f<0x143, 0xc>(0.f, x), mk[5], x); } while (0)
+#pragma unroll
+    for (int k = 0; k < 10; k++) SEG_SCAN(acc[k]);
+#pragma unroll
+    for (int k = 0; k < 48; k++) if (k < 3 * nsh) SEG_SCAN(ash[k]);
+#undef SEG_SCAN
+    bool same[1];
+    { const int gp = __shfl_up(g, 1); same[0] = (lane >= 1) && (gp == g); }
     const int gn = __shfl_down(g, 1);
     const bool tail = live && (lane == 63 || gn != g);
     // run head of this lane's run (all lanes take part in the ballot, so it precedes the early return)
