@@ -264,6 +264,11 @@ __device__ __forceinline__ float dpp_f(float old, float src)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xf, false));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_z(float src)        // bound_ctrl: lanes without a source read 0 (lets the compiler fold the move into the consumer)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_incl_prod(float x)
 {
     x *= dpp_f<0x111, 0xf>(1.f, x); x *= dpp_f<0x112, 0xf>(1.f, x); x *= dpp_f<0x114, 0xf>(1.f, x); x *= dpp_f<0x118, 0xf>(1.f, x);
@@ -655,8 +660,8 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
         mk[4] = gA == g ? 1.f : 0.f; mk[5] = gB == g ? 1.f : 0.f;
     }
 #define SEG_SCAN(x) do { \
-        x = fmaf(dpp_f<0x111, 0xf>(0.f, x), mk[0], x); x = fmaf(dpp_f<0x112, 0xf>(0.f, x), mk[1], x); \
-        x = fmaf(dpp_f<0x114, 0xf>(0.f, x), mk[2], x); x = fmaf(dpp_f<0x118, 0xf>(0.f, x), mk[3], x); \
+        x = fmaf(dpp_z<0x111>(x), mk[0], x); x = fmaf(dpp_z<0x112>(x), mk[1], x); \
+        x = fmaf(dpp_z<0x114>(x), mk[2], x); x = fmaf(dpp_z<0x118>(x), mk[3], x); \
         x = fmaf(dpp_f<0x142, 0xa>(0.f, x), mk[4], x); x = fmaf(dpp_f<0x143, 0xc>(0.f, x), mk[5], x); } while (0)
 #pragma unroll
     for (int k = 0; k < 10; k++) SEG_SCAN(acc[k]);
