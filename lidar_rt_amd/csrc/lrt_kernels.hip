@@ -1230,8 +1230,11 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
         hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, st->bounds, st->keys_a, st->vals_a);
         size_t tmp = st->sort_tmp_bytes;
         // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
-        // the top 32 bits of the 63-bit code (10-11 bits per axis) order the primitives; four 8-bit onesweep passes
-        HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, LRT_SORT_LO_BIT, 63, stream));
+        // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
+        // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
+        int pbits = 1; while ((1ll << pbits) < (long long)P) pbits++;
+        int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
+        HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 63 - sort_bits, 63, stream));
         hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
