@@ -64,7 +64,8 @@ struct lrt_state {
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
     float* nodes; float* nodes_aos; size_t cap_nodes;
-    unsigned* bounds;    // 6 ordered-uint (min xyz, max xyz)
+    unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
+    int bounds_sel;
     unsigned* tile_counter;
     unsigned long long* stats;   // 8 counters
     int stats_enabled;
@@ -125,9 +126,10 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
 }
 
 __global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
-                         const unsigned* __restrict__ bounds, uint64_t* keys, uint32_t* vals)
+                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
     if (g >= P) return;
     float lo[3], ext = 0.f;
     for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
@@ -1055,7 +1057,8 @@ lrt_state* lrt_create(int device)
     st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9;
     st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
     st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0; st->hit_ovf_host[2] = 0; st->hit_ovf_host[3] = 0;
-    if (hipMalloc(&st->bounds, 6 * sizeof(unsigned)) != hipSuccess ||
+    const unsigned bounds_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    if (hipMalloc(&st->bounds, 12 * sizeof(unsigned)) != hipSuccess || hipMemcpy(st->bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hipMalloc failed");
@@ -1223,11 +1226,12 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     if (P > 0) {
-        HIPCHK(hipMemsetAsync(st->bounds, 0xff, 3 * sizeof(unsigned), stream));
-        HIPCHK(hipMemsetAsync(st->bounds + 3, 0x00, 3 * sizeof(unsigned), stream));
+        unsigned* bcur = st->bounds + 6 * (st->bounds_sel & 1);    // two sets: k_morton re-arms the other one for the next build
+        unsigned* bnext = st->bounds + 6 * ((st->bounds_sel + 1) & 1);
+        st->bounds_sel ^= 1;
         int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
-        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, st->bounds);
-        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, st->bounds, st->keys_a, st->vals_a);
+        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur);
+        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a);
         size_t tmp = st->sort_tmp_bytes;
         // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
         // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean

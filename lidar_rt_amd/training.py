@@ -273,9 +273,22 @@ def _quaternions_with_normal(n: torch.Tensor) -> torch.Tensor:
     a2 = a * torch.cos(ang)[:, None] + b * torch.sin(ang)[:, None]
     b2 = torch.cross(n, a2, dim=1)
     R = torch.stack([a2, b2, n], -1)                                   # columns = axes
-    w = torch.sqrt(torch.clamp_min(1 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2], 1e-8)) / 2
-    q = torch.stack([w, (R[:, 2, 1] - R[:, 1, 2]) / (4 * w), (R[:, 0, 2] - R[:, 2, 0]) / (4 * w), (R[:, 1, 0] - R[:, 0, 1]) / (4 * w)], -1)
-    return F.normalize(q, dim=1)
+    return F.normalize(_matrix_to_quaternion(R), dim=1)
+
+
+def _matrix_to_quaternion(R: torch.Tensor) -> torch.Tensor:
+    """(N,3,3) rotations -> (N,4) (w,x,y,z); picks the numerically largest component first (stable near 180 degrees)."""
+    m00, m11, m22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    q2 = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)   # 4 w^2, 4 x^2, ...
+    cand = torch.stack([
+        torch.stack([q2[:, 0], R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], -1),
+        torch.stack([R[:, 2, 1] - R[:, 1, 2], q2[:, 1], R[:, 1, 0] + R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0]], -1),
+        torch.stack([R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] + R[:, 0, 1], q2[:, 2], R[:, 2, 1] + R[:, 1, 2]], -1),
+        torch.stack([R[:, 1, 0] - R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0], R[:, 2, 1] + R[:, 1, 2], q2[:, 3]], -1)], 1)    # (N,4,4)
+    best = q2.argmax(1)
+    q = cand[torch.arange(R.shape[0], device=R.device), best]
+    q = q / (2 * torch.sqrt(q2.gather(1, best[:, None]).clamp_min(1e-12)))
+    return torch.where(q[:, :1] < 0, -q, q)
 
 
 class GaussianScene:
