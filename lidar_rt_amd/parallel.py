@@ -142,6 +142,21 @@ class ShardedTracer:
                 self.last_exchange = "dense"
         return lay.views
 
+    def _all_gather_rows(self, t: torch.Tensor):
+        """all_gather of equally shaped tensors; one flat receive buffer when the backend offers it (RCCL), so that the
+        collective is a single large message without a per-rank copy."""
+        world = self.world
+        if t.is_cuda:
+            try:
+                out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() > 0 else out, t, group=self.group)
+                return [out[r] for r in range(world)]
+            except (RuntimeError, NotImplementedError, AttributeError):
+                pass                                                  # e.g. gloo with device tensors: fall through
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=self.group)
+        return parts
+
     def _exchange_sparse(self, lay: GradLayout) -> bool:
         """Sum the ranks' partial gradients by exchanging only the rows of touched Gaussians.
 
@@ -171,10 +186,7 @@ class ShardedTracer:
                 pay[:m, col:col + k] = lay.views[name].reshape(P, k).index_select(0, idx)
                 col += k
             ids[:m] = idx.to(torch.int32)
-        pays = [torch.empty_like(pay) for _ in range(world)]
-        idss = [torch.empty_like(ids) for _ in range(world)]
-        dist.all_gather(pays, pay, group=self.group)
-        dist.all_gather(idss, ids, group=self.group)
+        pays, idss = self._all_gather_rows(pay), self._all_gather_rows(ids)
         lay.flat.zero_()
         for r in range(world):                                        # fixed order -> identical rounding on every rank
             c = counts[r]
