@@ -183,7 +183,7 @@ class GaussianAsset:
     # ---- densification --------------------------------------------------------------------------------------------
     def add_densification_stats(self, mean_grads: torch.Tensor, update_filter: torch.Tensor):
         self.xyz_gradient_accum += torch.norm(mean_grads, dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        self.denom += update_filter.reshape(-1, 1).to(self.denom.dtype)       # == denom[update_filter] += 1, without nonzero()
 
     def _select(self, mask):
         return {n: t.detach()[mask] for n, t in self._params().items()}

@@ -45,5 +45,5 @@ rows = [(e.key, e.device_time_total / 3.0, e.count / 3) for e in prof.key_averag
 rows.sort(key=lambda r: -r[1])
 tot = sum(r[1] for r in rows)
 print(f"GPU kernel time per iteration: {tot / 1e3:.2f} ms")
-for k, us, c in rows[:22]:
+for k, us, c in rows[:int(os.environ.get('ROWS', '22'))]:
     print(f"  {us:8.1f} us  x{c:4.1f}  {k[:90]}")
