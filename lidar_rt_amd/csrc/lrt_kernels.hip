@@ -82,7 +82,7 @@ struct lrt_state {
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -1101,6 +1101,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
         int l2 = -1;
@@ -1358,7 +1359,12 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)
-            const int max_blocks = wg4 ? 256 * st->wg4_per_cu : 256 * 16;
+            // k_fwd_cr4: 8 waves per tile when every workgroup would get at most one tile anyway (few tiles: the launch lasts as
+            // long as its heaviest tile), else 4
+            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 8 ? 8 : 4));
+            const int per_cu = nw == 8 ? (st->wg4_per_cu + 1) / 2 : st->wg4_per_cu;
+            if (wg4 && tp.c4_qlimit < 32u * (unsigned)nw + 8u) tp.c4_qlimit = 32u * (unsigned)nw + 8u;   // room for one round's appends
+            const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
             int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;
             if (blocks > st->cr_blocks_cap) {
                 HIPCHK(hipStreamSynchronize(stream));
@@ -1371,22 +1377,28 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             tp.cr_lists = st->cr_lists;
             if (getenv("LRT_DEBUG_OCC")) {
                 int n0 = -1, n1 = -1, n2 = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<false>, 64 * C4_NW, 0);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true>, 64 * C4_NW, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<true, 4>, 256, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true, 8>, 512, 0);
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_fwd_cr<true>, 64, 0);
-                fprintf(stderr, "[lrt] occupancy blocks/CU: k_fwd_cr4<false> %d, k_fwd_cr4<true> %d, k_fwd_cr<true> %d; launching %d blocks\n", n0, n1, n2, blocks);
+                fprintf(stderr, "[lrt] occupancy blocks/CU: k_fwd_cr4<true,4> %d, k_fwd_cr4<true,8> %d, k_fwd_cr<true> %d; launching %d blocks of %d waves\n", n0, n1, n2, blocks, nw);
             }
             ScopedTimer tm(st, 1, stream);
             const float* rec_ = (const float*)st->rec; const float* naos_ = (const float*)st->nodes_aos;
-            if (defer && record) {
-                if (wg4) hipLaunchKernelGGL(k_fwd_cr4<true>, dim3(blocks), dim3(64 * C4_NW), 0, stream, tp, rec_, naos_);
-                else hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
+            const bool dfr = defer && record;
+            if (wg4 && nw == 8) {
+                if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
+                else hipLaunchKernelGGL((k_fwd_cr4<false, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
+            } else if (wg4) {
+                if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
+                else hipLaunchKernelGGL((k_fwd_cr4<false, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
+            } else {
+                if (dfr) hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
+                else hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
+            }
+            if (dfr) {
                 const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
                 hipLaunchKernelGGL(k_fwd_colour_ovf, dim3(256), dim3(256), 0, stream, tp);
-            } else {
-                if (wg4) hipLaunchKernelGGL(k_fwd_cr4<false>, dim3(blocks), dim3(64 * C4_NW), 0, stream, tp, rec_, naos_);
-                else hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
             }
         }
         HIPCHK(hipGetLastError());

@@ -26,7 +26,8 @@ if torch.cuda.is_available():
 MODES = [{"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 1, "bwd_mode": 1, "defer_colour": 0},
          {"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
-         {"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 1}]
+         {"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 1},
+         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8}]
 GRADS = ("means", "scales", "rotations", "opacities", "shs")
 
 
@@ -46,7 +47,7 @@ def s10k():
     return sc, o, d, dL
 
 
-@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else ""))
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else ""))
 @pytest.mark.parametrize("deg,bg", [(3, (0, 0, 1)), (0, (0, 0, 0)), (1, (0.3, 0.7, 0.2)), (2, (0, 0, 1))])
 def test_s10k_forward_backward_match_oracle(s10k, mode, deg, bg):
     sc, o, d, dL = s10k
@@ -240,10 +241,10 @@ def test_unrecoverable_overflow_is_reported_loudly(s10k):
     sc, o, d, dL = s10k
     tr = Tracer()
     with pytest.raises(LrtError, match="internal overflow"):
-        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, opts={"c4_queue_limit": 136}, tracer=tr, training=False)
+        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, opts={"c4_queue_limit": 136, "c4_waves": 4}, tracer=tr, training=False)
     tr.train()
     with pytest.raises(LrtError, match="internal overflow"):
-        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 136}, tracer=tr)
+        run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 136, "c4_waves": 4}, tracer=tr)
     h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, tracer=tr)                 # the state recovers with sane options
     assert not np.isnan(h["out"]).any()
 
@@ -253,7 +254,7 @@ def test_queue_overflow_falls_back_to_narrower_slabs(s10k):
     artificially small limit this happens on many tiles and the result must not change."""
     sc, o, d, dL = s10k
     a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
-    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 200})
+    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_queue_limit": 200, "c4_waves": 4})
     assert rel_l2(b["out"], a["out"]) < 1e-6 and frac_outside(b["out"], a["out"], 1e-5) <= 1e-4
     for k in GRADS:
         assert rel_l2(b["grads"][k], a["grads"][k]) < 1e-5, k
