@@ -1336,7 +1336,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
             HIPCHK(hipMalloc(&st->hit_keys_sorted, kc * sizeof(unsigned long long)));
             size_t tmpb = 0;
-            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpb, st->hit_keys, st->hit_keys_sorted, kc, 0, 64, stream));
+            HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(nullptr, tmpb, st->hit_keys, st->hit_keys_sorted, kc, 0, 64, stream));
             st->bsort_tmp_bytes = tmpb + 256;
             HIPCHK(hipMalloc(&st->bsort_tmp, st->bsort_tmp_bytes));
             st->key_cap = (unsigned)(kc < 0xffffffffull ? kc : 0xffffffffull);
@@ -1482,7 +1482,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     size_t tmpb = st->bsort_tmp_bytes;
                     // only the Gaussian bits are sorted: the sort is stable and the ids ascend in the input, so the order inside a run
                     // is the same as a full-key sort would give (3 instead of 6 radix passes)
-                    HIPCHK(rocprim::radix_sort_keys(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
+                    HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
                     if (st->reduce_mode == 0) {
                         const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
