@@ -108,6 +108,18 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
 /* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays). */
 int lrt_set_option(lrt_state* st, const char* name, int value);
 
+/* Sparse gradient exchange of the azimuth-sharded backward (lidar_rt_amd/parallel.py; not in the reference, which is
+ * single-GPU).  Row r of `rows` (n x (11 + 3M) floats) holds, for Gaussian idx[r]:
+ *   [d_means 3 | d_scales 2 | d_rotations 4 | d_opacities 1 | d_shs 3M | accum 1].
+ * lrt_grad_gather packs the rows of the listed Gaussians; lrt_grad_scatter_add adds rows into the dense tensors (indices
+ * must be unique within one call: plain read-modify-write, so that calling it once per rank in rank order gives
+ * bit-identical sums on every replica). */
+int lrt_grad_gather(int device, int P, int M, int n, const int32_t* idx, const float* d_means, const float* d_scales,
+                    const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum,
+                    float* rows, void* stream);
+int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, const float* rows, float* d_means,
+                         float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -701,6 +701,23 @@ __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sparse gradient exchange helpers (azimuth-sharded backward): row r <-> Gaussian idx[r], see include/lrt.h.
+struct GradFields { float* f[6]; int w[6]; };               // means, scales, rotations, opacities, shs, accum
+template <bool GATHER>
+__global__ void __launch_bounds__(256) k_grad_rows(int n, int width, const int32_t* __restrict__ idx, GradFields g, float* rows)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * width) return;
+    const int r = (int)(t / width);
+    int e = (int)(t - (long long)r * width);
+    const int gi = idx[r];
+    int k = 0;
+    while (e >= g.w[k]) { e -= g.w[k]; k++; }
+    float* p = g.f[k] + (size_t)gi * g.w[k] + e;
+    if (GATHER) rows[t] = *p; else *p += rows[t];
+}
+
 #define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
 
 template <bool BWD>
@@ -1128,6 +1145,41 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
 
 /* Serial number of the most recent lrt_forward on this state (the hit record belongs to that forward). */
 long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
+
+static int grad_rows(const char* fn, bool gather, int device, int P, int M, int n, const int32_t* idx, float* rows, float* d_means,
+                     float* d_scales, float* d_rots, float* d_opac, float* d_shs, float* accum, void* stream_)
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) LRT_FAIL(LRT_ERR_ARG, "%s: no HIP device %d", fn, device);
+    if (P < 0 || M < 0 || n < 0 || n > P) LRT_FAIL(LRT_ERR_ARG, "%s: bad sizes P=%d M=%d n=%d", fn, P, M, n);
+    if (n == 0) return LRT_OK;
+    if (!idx || !rows || !d_means || !d_scales || !d_rots || !d_opac || !accum || (M > 0 && !d_shs)) LRT_FAIL(LRT_ERR_ARG, "%s: null pointer", fn);
+    HIPCHK(hipSetDevice(device));
+    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rots; g.w[2] = 4; g.f[3] = d_opac; g.w[3] = 1;
+    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
+    const int width = 11 + 3 * M;
+    const long long tot = (long long)n * width;
+    const int blocks = (int)((tot + 255) / 256);
+    if (gather) hipLaunchKernelGGL(k_grad_rows<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, n, width, idx, g, rows);
+    else hipLaunchKernelGGL(k_grad_rows<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, n, width, idx, g, rows);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+int lrt_grad_gather(int device, int P, int M, int n, const int32_t* idx, const float* d_means, const float* d_scales,
+                    const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum,
+                    float* rows, void* stream)
+{
+    return grad_rows("lrt_grad_gather", true, device, P, M, n, idx, rows, const_cast<float*>(d_means), const_cast<float*>(d_scales),
+                     const_cast<float*>(d_rotations), const_cast<float*>(d_opacities), const_cast<float*>(d_shs), const_cast<float*>(accum), stream);
+}
+
+int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, const float* rows, float* d_means,
+                         float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream)
+{
+    return grad_rows("lrt_grad_scatter_add", false, device, P, M, n, idx, const_cast<float*>(rows), d_means, d_scales, d_rotations,
+                     d_opacities, d_shs, accum, stream);
+}
 
 int lrt_check_forward(lrt_state* st, int wait)
 {

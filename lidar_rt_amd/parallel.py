@@ -142,6 +142,23 @@ class ShardedTracer:
                 self.last_exchange = "dense"
         return lay.views
 
+    @staticmethod
+    def _grad_rows(fn: str, lay: GradLayout, n: int, ids: torch.Tensor, rows: torch.Tensor):
+        """lrt_grad_gather / lrt_grad_scatter_add (include/lrt.h) on the views of the flat buffer."""
+        import ctypes as C
+        from . import _capi
+        v, p = lay.views, _capi.ptr
+        dev = rows.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        dense = (p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]))
+        lib = _capi.load()
+        if fn == "lrt_grad_gather":
+            rc = lib.lrt_grad_gather(idx, lay.P, lay.M, int(n), p(ids), *dense, p(rows), stream)
+        else:
+            rc = lib.lrt_grad_scatter_add(idx, lay.P, lay.M, int(n), p(ids), p(rows), *dense, stream)
+        _capi.check(rc, fn)
+
     def _all_gather_rows(self, t: torch.Tensor):
         """all_gather of equally shaped tensors; one flat receive buffer when the backend offers it (RCCL), so that the
         collective is a single large message without a per-rank copy."""
@@ -180,17 +197,24 @@ class ShardedTracer:
         pay = torch.zeros((max(nmax, 1), width), dtype=torch.float32, device=dev)
         ids = torch.zeros(max(nmax, 1), dtype=torch.int32, device=dev)
         m = idx.numel()
+        hip = dev.type == "cuda"                                      # HIP tensors: one pack launch and one add launch per rank
         if m:
-            col = 0
-            for name, k in fields:
-                pay[:m, col:col + k] = lay.views[name].reshape(P, k).index_select(0, idx)
-                col += k
             ids[:m] = idx.to(torch.int32)
+            if hip:
+                self._grad_rows("lrt_grad_gather", lay, m, ids, pay)
+            else:
+                col = 0
+                for name, k in fields:
+                    pay[:m, col:col + k] = lay.views[name].reshape(P, k).index_select(0, idx)
+                    col += k
         pays, idss = self._all_gather_rows(pay), self._all_gather_rows(ids)
         lay.flat.zero_()
         for r in range(world):                                        # fixed order -> identical rounding on every rank
             c = counts[r]
             if c == 0:
+                continue
+            if hip:
+                self._grad_rows("lrt_grad_scatter_add", lay, c, idss[r], pays[r])
                 continue
             ridx = idss[r][:c].long()
             col = 0

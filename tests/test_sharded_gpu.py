@@ -27,5 +27,6 @@ def _bench(world):
 def test_two_ranks_on_one_gpu_match_single_rank():
     a, b = _bench(1), _bench(2)
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["config"]["gradient_exchange"] == "sparse"               # all_gather of the touched rows, packed / added by the HIP kernels
     for k in ("out", "d_means", "d_shs", "accum"):
         assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (k, a["checksums"], b["checksums"])
