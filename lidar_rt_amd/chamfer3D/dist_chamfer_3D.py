@@ -1,53 +1,47 @@
-"""Host side of the Chamfer operator: the counterpart of the reference's
-lib/utils/chamfer3D/dist_chamfer_3D.py:31-82 (`chamfer_3DFunction`, `chamfer_3DDist`), same names, argument
-meaning and return tuple, over the MI355X C ABI instead of a JIT-compiled CUDA extension.
+"""Host side of the Chamfer operator on the MI355X C ABI.
 
-    dist1, dist2, idx1, idx2 = chamfer_3DDist()(xyz1, xyz2)      # (B,N,3), (B,M,3) float32 HIP tensors
-
-dist are SQUARED nearest-neighbour distances (the reference's convention, metric_utils.py:18-19), idx int32.
+Public names and call contract follow the reference's wrapper (lib/utils/chamfer3D/dist_chamfer_3D.py:31-82) so that
+``chamLoss = chamfer_3DDist(); dist1, dist2, idx1, idx2 = chamLoss(a, b)`` (train.py:197-205, eval.py:355-359) reads the
+same: ``a`` (B,N,3), ``b`` (B,M,3) float32 HIP tensors -> SQUARED nearest-neighbour distances (B,N), (B,M) (the
+reference's convention, metric_utils.py:18-19) and int32 neighbour indices.  The autograd rule is the analytic one of
+chamfer3D.cu:154-173; the index outputs carry no gradient.
 """
 from __future__ import annotations
 
 import torch
-from torch import nn
-from torch.autograd import Function
 
 from . import _C as chamfer_3D
 
 
-class chamfer_3DFunction(Function):
+def _nearest(a: torch.Tensor, b: torch.Tensor):
+    """Allocate the four outputs and run the forward kernels."""
+    if a.dim() != 3 or b.dim() != 3 or a.size(2) != 3 or b.size(2) != 3:
+        raise AssertionError("Wrong last dimension for the chamfer distance 's input! Check with .size()")
+    shape_a, shape_b = a.shape[:2], b.shape[:2]
+    new = lambda shape, dtype: torch.empty(shape, device=a.device, dtype=dtype)
+    res = (new(shape_a, torch.float32), new(shape_b, torch.float32), new(shape_a, torch.int32), new(shape_b, torch.int32))
+    chamfer_3D.forward(a, b, *res)
+    return res
+
+
+class chamfer_3DFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz1, xyz2):
-        batchsize, n, dim = xyz1.size()
-        assert dim == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
-        _, m, dim = xyz2.size()
-        assert dim == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
-        device = xyz1.device
-        dist1 = torch.empty(batchsize, n, device=device, dtype=torch.float32)
-        dist2 = torch.empty(batchsize, m, device=device, dtype=torch.float32)
-        idx1 = torch.empty(batchsize, n, device=device, dtype=torch.int32)
-        idx2 = torch.empty(batchsize, m, device=device, dtype=torch.int32)
-        chamfer_3D.forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
-        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
-        ctx.mark_non_differentiable(idx1, idx2)
-        return dist1, dist2, idx1, idx2
+        d_ab, d_ba, nn_ab, nn_ba = _nearest(xyz1, xyz2)
+        ctx.save_for_backward(xyz1, xyz2, nn_ab, nn_ba)
+        ctx.mark_non_differentiable(nn_ab, nn_ba)
+        return d_ab, d_ba, nn_ab, nn_ba
 
     @staticmethod
-    def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
-        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        graddist1 = graddist1.contiguous()
-        graddist2 = graddist2.contiguous()
-        gradxyz1 = torch.zeros_like(xyz1)
-        gradxyz2 = torch.zeros_like(xyz2)
-        chamfer_3D.backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
-        return gradxyz1, gradxyz2
+    def backward(ctx, g_ab, g_ba, _g_nn_ab, _g_nn_ba):
+        a, b, nn_ab, nn_ba = ctx.saved_tensors
+        grad_a, grad_b = torch.zeros_like(a), torch.zeros_like(b)        # the kernels accumulate into them
+        chamfer_3D.backward(a, b, grad_a, grad_b, g_ab.contiguous(), g_ba.contiguous(), nn_ab, nn_ba)
+        return grad_a, grad_b
 
 
-class chamfer_3DDist(nn.Module):
-    def __init__(self):
-        super(chamfer_3DDist, self).__init__()
+class chamfer_3DDist(torch.nn.Module):
+    """``forward(input1, input2)`` -> ``(dist1, dist2, idx1, idx2)``."""
 
     def forward(self, input1, input2):
-        input1 = input1.contiguous()
-        input2 = input2.contiguous()
-        return chamfer_3DFunction.apply(input1, input2)
+        return chamfer_3DFunction.apply(input1.contiguous(), input2.contiguous())
