@@ -60,6 +60,14 @@ void lrt_destroy(lrt_state* st);
 int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
               const float* opacities, float scale_modifier, void* stream);
 
+/* The same build for a tracer that will only see the given rays (one rank's azimuth slab of a sharded frame; not in the
+ * reference): Gaussians whose bounding sphere lies outside the cone around the rays are left out of the LBVH (conservative:
+ * results are unchanged).  ray_o, ray_d (n_rays,3).  Costs one 4-byte device->host read-back (the sort and the tree are sized
+ * by the kept count); cones wider than ~80 degrees keep everything. */
+int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
+                       const float* opacities, float scale_modifier, int n_rays, const float* ray_o, const float* ray_d,
+                       void* stream);
+
 /* Forward trace.  Requires a prior lrt_build with the same P.
  *   ray_o, ray_d (H,W,3); shs (P,M,3); sh_degree in 0..3, (sh_degree+1)^2 <= M;
  *   background: device pointer to 3 floats.
@@ -84,6 +92,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
  * uses belongs to THAT forward: a caller that runs several forwards before a backward compares the serial it saved
  * and, on mismatch, sets option "invalidate_record" so that lrt_backward re-traces instead. */
 long long lrt_forward_serial(lrt_state* st);
+
+/* Primitives in the current LBVH (= P after lrt_build, the kept count after lrt_build_for_rays; -1: nothing built). */
+int lrt_built_count(lrt_state* st);
 
 /* Overflow status of the most recent lrt_forward (the kernels only raise a device flag; lrt_backward checks it too).
  * wait != 0: block until that forward has finished; wait == 0: report only if it already has.  Returns LRT_ERR_STATE with

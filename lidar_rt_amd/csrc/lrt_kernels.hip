@@ -66,6 +66,7 @@ struct lrt_state {
     float* nodes; float* nodes_aos; size_t cap_nodes;
     unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
     int bounds_sel;
+    unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
     unsigned* tile_counter;
     unsigned long long* stats;   // 8 counters
     int stats_enabled;
@@ -100,13 +101,86 @@ __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >
 __device__ __forceinline__ unsigned wave_sum_u(unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 
 // ---------------------------------------------------------------------------------------------------
+// Ray-cone culling for builds that serve only a subset of the frame's rays (one rank's azimuth slab): Gaussians whose
+// bounding sphere lies outside the cone around the rays cannot be hit and are left out of the LBVH.
+// cone words: [0..2] sum of unit directions (float), [3..5] / [6..8] min / max origin (ordered uint), [9] min cos(angle to the
+// axis) (ordered uint), [10] kept primitives (uint).
+__global__ void k_cone_init(unsigned* cone)
+{
+    const int i = threadIdx.x;
+    if (i < 3) cone[i] = 0u; else if (i < 6) cone[i] = 0xffffffffu; else if (i < 9) cone[i] = 0u;
+    else if (i == 9) cone[i] = 0xffffffffu; else if (i == 10) cone[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256) k_cone_axis(int n, const float* __restrict__ ro, const float* __restrict__ rd, unsigned* cone)
+{
+    float s[3] = {0.f, 0.f, 0.f}, lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const float dx = rd[3 * (size_t)r], dy = rd[3 * (size_t)r + 1], dz = rd[3 * (size_t)r + 2];
+        const float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f));
+        s[0] += dx * inv; s[1] += dy * inv; s[2] += dz * inv;
+        for (int i = 0; i < 3; i++) { const float o = ro[3 * (size_t)r + i]; lo[i] = fminf(lo[i], o); hi[i] = fmaxf(hi[i], o); }
+    }
+    for (int i = 0; i < 3; i++) {
+        for (int o = 32; o > 0; o >>= 1) s[i] += __shfl_xor(s[i], o);
+        lo[i] = wave_min(lo[i]); hi[i] = wave_max(hi[i]);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 3; i++) {
+            atomicAdd(reinterpret_cast<float*>(cone) + i, s[i]);
+            atomicMin(cone + 3 + i, f2ord(lo[i])); atomicMax(cone + 6 + i, f2ord(hi[i]));
+        }
+}
+
+__global__ void __launch_bounds__(256) k_cone_angle(int n, const float* __restrict__ rd, unsigned* cone)
+{
+    const float* sm = reinterpret_cast<const float*>(cone);
+    const float an = rsqrtf(fmaxf(sm[0] * sm[0] + sm[1] * sm[1] + sm[2] * sm[2], 1e-30f));
+    const float ax = sm[0] * an, ay = sm[1] * an, az = sm[2] * an;
+    float mc = 1.f;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const float dx = rd[3 * (size_t)r], dy = rd[3 * (size_t)r + 1], dz = rd[3 * (size_t)r + 2];
+        mc = fminf(mc, (dx * ax + dy * ay + dz * az) * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f)));
+    }
+    mc = wave_min(mc);
+    if ((threadIdx.x & 63) == 0) atomicMin(cone + 9, f2ord(mc));
+}
+
+// true = the Gaussian (centre, quad half-diagonal rho) cannot be hit by any ray of the cone (conservative).
+__device__ __forceinline__ bool cone_culls(const unsigned* __restrict__ cone, float x, float y, float z, float rho)
+{
+    const float* sm = reinterpret_cast<const float*>(cone);
+    const float s2 = sm[0] * sm[0] + sm[1] * sm[1] + sm[2] * sm[2];
+    const float mincos = ord2f(cone[9]);
+    if (!(s2 > 1e-12f) || !(mincos > 0.17f)) return false;             // no usable axis, or a cone wider than ~80 degrees: keep everything
+    const float an = rsqrtf(s2);
+    float o[3], ro2 = 0.f;
+    for (int i = 0; i < 3; i++) { const float l = ord2f(cone[3 + i]), h = ord2f(cone[6 + i]); o[i] = 0.5f * (l + h); ro2 += 0.25f * (h - l) * (h - l); }
+    const float vx = x - o[0], vy = y - o[1], vz = z - o[2];
+    const float L = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float R = rho * 1.001f + sqrtf(ro2) + 1e-3f;                 // rays may start anywhere in the origins' bounding box
+    if (!(L > R)) return false;
+    const float ct = fminf(1.f, fmaxf(-1.f, (vx * sm[0] + vy * sm[1] + vz * sm[2]) * an / L));
+    const float half = acosf(fminf(1.f, mincos)) + 2e-3f;
+    return acosf(ct) > half + asinf(fminf(1.f, R / L)) + 1e-4f;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LBVH build
-__global__ void k_bounds(int P, const float* __restrict__ means, const float* __restrict__ opac, unsigned* bounds)
+__device__ __forceinline__ float quad_half_diag(const float* __restrict__ scales, const float* __restrict__ opac, int g)
+{
+    const float f = lrt_cutoff(opac[g]), ex = scales[2 * (size_t)g] * f, ey = scales[2 * (size_t)g + 1] * f;
+    return sqrtf(ex * ex + ey * ey);
+}
+
+__global__ void k_bounds(int P, const float* __restrict__ means, const float* __restrict__ opac, unsigned* bounds,
+                         const float* __restrict__ scales, const unsigned* __restrict__ cone)
 {
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P; g += gridDim.x * blockDim.x) {
         float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
         bool ok = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
+        if (ok && cone) ok = !cone_culls(cone, x, y, z, quad_half_diag(scales, opac, g));
         if (ok) {
             lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
             hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
@@ -126,10 +200,36 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
 }
 
 __global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
-                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals)
+                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals,
+                         const float* __restrict__ scales, unsigned* __restrict__ cone)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
+    if (cone) {
+        // culled build: the kept primitives are compacted (one atomic per wave); their order is fixed by the sort afterwards
+        bool keep = false;
+        if (g < P) {
+            const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+            keep = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f &&
+                   !cone_culls(cone, x, y, z, quad_half_diag(scales, opac, g));
+        }
+        const unsigned long long m = __ballot(keep);
+        if (!m) return;
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(cone + 10, (unsigned)__popcll(m));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (!keep) return;
+        const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        float lo[3], ext = 0.f;
+        for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
+        const float sc_ = ext > 0.f ? 2097151.0f / ext : 0.f;
+        const uint32_t cx = (uint32_t)fminf(fmaxf((means[3 * g] - lo[0]) * sc_, 0.f), 2097151.f);
+        const uint32_t cy = (uint32_t)fminf(fmaxf((means[3 * g + 1] - lo[1]) * sc_, 0.f), 2097151.f);
+        const uint32_t cz = (uint32_t)fminf(fmaxf((means[3 * g + 2] - lo[2]) * sc_, 0.f), 2097151.f);
+        keys[slot] = lrt_morton63(cx, cy, cz); vals[slot] = (uint32_t)g;
+        return;
+    }
     if (g >= P) return;
     float lo[3], ext = 0.f;
     for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
@@ -1089,7 +1189,8 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->ctrl, st->stats, st->ovf_list};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
+    if (st->cone_host) (void)hipHostFree(st->cone_host);
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
@@ -1145,6 +1246,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
 
 /* Serial number of the most recent lrt_forward on this state (the hit record belongs to that forward). */
 long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
+
+int lrt_built_count(lrt_state* st) { return (st && st->P >= 0) ? st->P_built : -1; }
 
 static int grad_rows(const char* fn, bool gather, int device, int P, int M, int n, const int32_t* idx, float* rows, float* d_means,
                      float* d_scales, float* d_rots, float* d_opac, float* d_shs, float* accum, void* stream_)
@@ -1252,10 +1355,10 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
     const void* src = nullptr; long long bytes = 0;
     switch (which) {
-        case 0: src = st->vals_b; bytes = (long long)st->P * 4; break;
-        case 1: src = st->rec; bytes = (long long)st->P * LRT_REC_FLOATS * 4; break;
+        case 0: src = st->vals_b; bytes = (long long)st->P_built * 4; break;
+        case 1: src = st->rec; bytes = (long long)st->P_built * LRT_REC_FLOATS * 4; break;
         case 2: src = st->nodes; bytes = (long long)st->n_nodes * LRT_NODE_FLOATS * 4; break;
-        case 3: src = st->aabb; bytes = (long long)st->P * 6 * 4; break;
+        case 3: src = st->aabb; bytes = (long long)st->P_built * 6 * 4; break;
         case 4: src = st->dbg; bytes = (long long)st->dbg_floats * 4; break;
         default: LRT_FAIL(LRT_ERR_ARG, "lrt_debug_read: unknown buffer %d", which);
     }
@@ -1264,13 +1367,14 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
     return bytes;
 }
 
-int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rots,
-              const float* opac, float mod, void* stream_)
+static int build_impl(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots,
+                      const float* opac, float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_)
 {
-    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_build: null state");
-    if (P < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_build: negative P");
-    if (P > 0 && (!means || !scales || !rots || !opac)) LRT_FAIL(LRT_ERR_ARG, "lrt_build: null parameter pointer");
-    if (P >= (1 << 28)) LRT_FAIL(LRT_ERR_ARG, "lrt_build: P too large");
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "%s: null state", fn);
+    if (P < 0) LRT_FAIL(LRT_ERR_ARG, "%s: negative P", fn);
+    if (P > 0 && (!means || !scales || !rots || !opac)) LRT_FAIL(LRT_ERR_ARG, "%s: null parameter pointer", fn);
+    if (P >= (1 << 28)) LRT_FAIL(LRT_ERR_ARG, "%s: P too large", fn);
+    if (n_rays < 0 || (n_rays > 0 && (!ray_o || !ray_d))) LRT_FAIL(LRT_ERR_ARG, "%s: bad ray set", fn);
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_capacity(st, P, stream);
@@ -1278,31 +1382,60 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
     st->P = -1;
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
+    int Pk = P;                                                  // primitives that enter the LBVH
     if (P > 0) {
+        unsigned* cone = nullptr;
+        if (n_rays > 0) {                                        // cull against the cone around the given rays
+            if (!st->cone) { HIPCHK(hipMalloc(&st->cone, 16 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, sizeof(unsigned))); }
+            cone = st->cone;
+            int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
+            hipLaunchKernelGGL(k_cone_init, dim3(1), dim3(64), 0, stream, cone);
+            hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
+            hipLaunchKernelGGL(k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
+        }
         unsigned* bcur = st->bounds + 6 * (st->bounds_sel & 1);    // two sets: k_morton re-arms the other one for the next build
         unsigned* bnext = st->bounds + 6 * ((st->bounds_sel + 1) & 1);
         st->bounds_sel ^= 1;
         int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
-        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur);
-        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a);
-        size_t tmp = st->sort_tmp_bytes;
-        // sort on the top 39 Morton bits (13 bits / axis); ties keep input order (stable radix sort)
-        // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
-        // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
-        int pbits = 1; while ((1ll << pbits) < (long long)P) pbits++;
-        int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
-        HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 63 - sort_bits, 63, stream));
-        hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
+        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)cone);
+        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone);
+        if (cone) {                                              // the sort and the tree are sized by the kept count: one 4-byte read-back
+            HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            Pk = (int)*st->cone_host;
+            if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
+        }
+        if (Pk > 0) {
+            size_t tmp = st->sort_tmp_bytes;
+            // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
+            // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
+            int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
+            int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
+            HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
+            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
+        }
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
-    int total = tree_layout(P, &nl, &L, cnt, off);
-    if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
-    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
+    int total = tree_layout(Pk, &nl, &L, cnt, off);
+    if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "%s: node capacity exceeded", fn);
+    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
     for (int l = 2; l <= L; l++)    // one launch per level (a single-block loop over the small top levels measured slower)
         hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
-    st->P = P; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
+    st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
     return LRT_OK;
+}
+
+int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rots,
+              const float* opac, float mod, void* stream_)
+{
+    return build_impl("lrt_build", st, P, means, scales, rots, opac, mod, 0, nullptr, nullptr, stream_);
+}
+
+int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac,
+                       float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_)
+{
+    return build_impl("lrt_build_for_rays", st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
 }
 
 static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t stream)

@@ -80,6 +80,12 @@ class OptiXStateWrapper:
         for h in self._handles.values():
             self._lib.lrt_enable_stats(h, 1 if enable else 0)
 
+    def built_count(self, device=None) -> int:
+        """Primitives in the current LBVH of `device` (fewer than P after a ray-cone culled build)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        return int(self._lib.lrt_built_count(h))
+
     def get_stats(self, device=None):
         import ctypes as C
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -142,8 +148,11 @@ def build_acceleration_structure(state: OptiXStateWrapper, vertices: torch.Tenso
     state.handle(vertices.device)      # create the per-device state eagerly (errors surface here)
 
 
-def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, opacities, scale_modifier=1.0):
-    """Fused fast path: LBVH straight from the Gaussian parameters (no vertices tensor)."""
+def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, opacities, scale_modifier=1.0, cull_rays=None):
+    """Fused fast path: LBVH straight from the Gaussian parameters (no vertices tensor).
+
+    cull_rays = (ray_o, ray_d): build only what these rays can reach (lrt_build_for_rays; used by the azimuth-sharded
+    tracer, whose ranks see one slab each).  The structure is then valid for THOSE rays only: rebuild before tracing others."""
     for t, n in ((means3D, "means3D"), (scales, "scales"), (rotations, "rotations"), (opacities, "opacities")):
         _check_f32_cuda(t, n)
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -155,8 +164,18 @@ def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, o
     m, s, r, o = (means3D.detach().contiguous(), scales.detach().contiguous(), rotations.detach().contiguous(),
                   opacities.detach().contiguous())
     with torch.cuda.device(idx):
-        _capi.check(state._lib.lrt_build(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
-                                         float(scale_modifier), _stream_ptr()), "lrt_build")
+        if cull_rays is None:
+            _capi.check(state._lib.lrt_build(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
+                                             float(scale_modifier), _stream_ptr()), "lrt_build")
+        else:
+            ro, rd = cull_rays
+            _check_f32_cuda(ro, "cull ray_o"); _check_f32_cuda(rd, "cull ray_d")
+            ro, rd = ro.detach().contiguous(), rd.detach().contiguous()
+            if ro.numel() != rd.numel() or rd.numel() % 3:
+                raise RuntimeError("cull_rays must be two (...,3) tensors of the same size")
+            _capi.check(state._lib.lrt_build_for_rays(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
+                                                      float(scale_modifier), rd.numel() // 3, _capi.ptr(ro), _capi.ptr(rd),
+                                                      _stream_ptr()), "lrt_build_for_rays")
     state._dirty[idx] = False
     state._built_P[idx] = P
     # keep the inputs alive until the stream has consumed them (stream-ordered, no sync)

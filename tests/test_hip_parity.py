@@ -304,3 +304,33 @@ def test_two_forwards_before_backward(s10k):
     out1.backward(torch.as_tensor(dL, device=DEV))
     for k in GRADS:
         assert rel_l2(t[k].grad.cpu().numpy().reshape(bw[k].shape), bw[k]) < 1e-3
+
+
+@pytest.mark.parametrize("n_slabs", [4, 8])
+def test_ray_cone_culled_build_gives_the_same_results(n_slabs):
+    """lrt_build_for_rays (an N-way azimuth split builds the LBVH for its slab's rays only): conservative culling, so the
+    slab's image is bit-identical ((t, gidx) order) and the gradients agree up to summation order."""
+    from lidar_rt_amd.parallel import column_slab
+    sc = scenes.make_scene(30000, seed=31, radius_scale=0.3)
+    o, d = scenes.kitti_rays(16, 512)
+    dL = scenes.upstream_grad(16, 512)
+    t = {k: torch.as_tensor(v, device="cuda:0") for k, v in sc.items()}
+    for r in (0, n_slabs // 2, n_slabs - 1):
+        a_, b_ = column_slab(512, r, n_slabs)
+        os_, ds_, g_ = o[:, a_:b_].copy(), d[:, a_:b_].copy(), dL[:, a_:b_].copy()
+        full = run_hip(sc, os_, ds_, 3, scenes.BG_DEFAULT, g_)
+        tr = Tracer()
+        ro, rd = torch.as_tensor(os_, device="cuda:0"), torch.as_tensor(ds_, device="cuda:0")
+        from lidar_rt_amd.diff_lidar_tracer import _C
+        tt = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        _C.build_from_gaussians(tr.optix_context, tt["means"], tt["scales"], tt["rotations"], tt["opacities"], 1.0, cull_rays=(ro, rd))
+        from tests.hip_util import settings
+        out, acc = tr(ro, rd, None, tt["means"], torch.zeros_like(tt["means"]), shs=tt["shs"], opacities=tt["opacities"],
+                      scales=tt["scales"], rotations=tt["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+        out.backward(torch.as_tensor(g_, device="cuda:0"))
+        kept = tr.optix_context.built_count(torch.device("cuda:0"))
+        assert 0 < kept < 0.75 * 30000, kept                                   # something was actually left out
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), full["out"])
+        assert rel_l2(acc.cpu().numpy(), full["accum"]) < 1e-6
+        for k in GRADS:
+            assert rel_l2(tt[k].grad.cpu().numpy().reshape(full["grads"][k].shape), full["grads"][k]) < 1e-5, k

@@ -26,10 +26,11 @@ for N in (1, 2, 4, 8):
         be.state.enable_timing(True)
         for it in range(6):
             if it == 2: be.state.get_timing(dev)          # drop the warm-up samples
-            be.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+            be.build(t["means"], t["scales"], t["rotations"], t["opacities"], cull_rays=(o, d) if (N >= 3 and os.environ.get("CULL", "0") == "1") else None)
             out, acc = be.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
             be.backward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, out, g, grads_out=grads)
         torch.cuda.synchronize()
         tm = be.state.get_timing(dev)
         f = lambda k: tm[k][0] / max(tm[k][1], 1)
-        print(f"N={N} rank {r}: cols {b - a:4d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms")
+        kept = be.state.built_count(dev)
+        print(f"N={N} rank {r}: cols {b - a:4d}  kept {kept:7d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms")
