@@ -352,6 +352,39 @@ class RangeFrames:
         self.mask_index: Dict[int, torch.Tensor] = {}
         self.sensor_center: Dict[int, torch.Tensor] = {}
 
+    @staticmethod
+    def range_rays(H: int, W: int, inclination, sensor2world: torch.Tensor, data_type: str = "KITTI",
+                   sensor2ego: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The (H,W,3) ray grid of a spinning LiDAR range image (lib/scene/lidar_sensor.py:395-434): column w has azimuth
+        (W-w-off)/W 2pi - pi - yaw, row h the inclination interpolated between the two bounds ((H-h-off)/H) or taken from a
+        per-beam table (flipped: row 0 = last entry); ``off`` = 0.5 pixel and ``yaw`` = atan2 of the sensor-to-ego rotation
+        for Waymo data (:42-49), 0 for KITTI; directions are rotated by ``sensor2world`` and normalised, the origin is
+        its translation.  Float32 arithmetic in the reference's order (the golden ray fixtures are matched to 1e-6)."""
+        dev = sensor2world.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        waymo = data_type == "Waymo"
+        off = 0.5 if waymo else 0.0
+        yaw = torch.atan2(sensor2ego[1, 0], sensor2ego[0, 0]) if waymo else 0.0
+        x = (torch.arange(W, 0, -1, **f32) - off) / float(W)
+        gy, gx = torch.meshgrid(torch.ones(H, **f32), x, indexing="ij")
+        azimuth = gx * 2 * torch.pi - torch.pi - yaw
+        inc = list(inclination) if isinstance(inclination, (list, tuple)) else [-float(inclination), float(inclination)]
+        if len(inc) == 2:
+            gy = gy * (torch.arange(H, 0, -1, **f32).unsqueeze(-1) - off) / float(H)
+            incl = gy * (inc[1] - inc[0]) + inc[0]
+        else:
+            incl = gy * torch.tensor(inc, **f32).flip(0).unsqueeze(-1)
+        d = torch.stack([torch.cos(incl) * torch.cos(azimuth), torch.cos(incl) * torch.sin(azimuth), torch.sin(incl)], dim=-1)
+        d = d @ sensor2world[:3, :3].T
+        d = d / torch.norm(d, dim=-1, keepdim=True)
+        o = sensor2world[:3, 3][None, None, :].expand(H, W, 3)
+        return o.contiguous(), d.contiguous()
+
+    def add_range_image(self, frame, depth, intensity, mask, inclination, sensor2world, data_type="KITTI", sensor2ego=None):
+        """A frame given as range image + sensor pose (what the reference's loaders put into LiDARSensor)."""
+        o, d = self.range_rays(depth.shape[0], depth.shape[1], inclination, sensor2world, data_type, sensor2ego)
+        self.add_frame(frame, o, d, depth, intensity, mask)
+
     def add_frame(self, frame, rays_o, rays_d, depth, intensity, mask):
         self.rays[frame] = (rays_o, rays_d)
         self.depth[frame], self.intensity[frame], self.mask[frame] = depth, intensity, mask.bool()

@@ -133,6 +133,28 @@ def test_ssim_and_range_frames():
     assert fr.train_frames == [7] and fr.get_range_rays(7)[1] is d
 
 
+def test_range_ray_grid_matches_the_reference_sensor():
+    """RangeFrames.range_rays against the golden grids produced by the reference's LiDARSensor.get_range_rays
+    (tests/golden/rays_*.npz: KITTI bounds mode, a posed KITTI sensor, Waymo per-beam table with yaw and half-pixel offsets)."""
+    import math, os
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    kb = [math.radians(-24.9), math.radians(2.0)]
+    g = np.load(os.path.join(gd, "rays_kitti_16x256.npz"))
+    o, d = training.RangeFrames.range_rays(16, 256, kb, torch.eye(4))
+    np.testing.assert_allclose(d.numpy(), g["ray_d"], atol=2e-6); np.testing.assert_array_equal(o.numpy(), g["ray_o"])
+    g = np.load(os.path.join(gd, "rays_kitti_posed_8x32.npz"))
+    o, d = training.RangeFrames.range_rays(8, 32, kb, torch.from_numpy(g["sensor2world"]))
+    np.testing.assert_allclose(d.numpy(), g["ray_d"], atol=2e-6); np.testing.assert_allclose(o.numpy(), g["ray_o"], atol=1e-7)
+    g = np.load(os.path.join(gd, "rays_waymo_8x40.npz"))
+    s2w = torch.from_numpy(g["sensor2world"])
+    o, d = training.RangeFrames.range_rays(8, 40, g["beam_inclinations"].tolist(), s2w, "Waymo", sensor2ego=s2w)
+    np.testing.assert_allclose(d.numpy(), g["ray_d"], atol=2e-6); np.testing.assert_allclose(o.numpy(), g["ray_o"], atol=1e-7)
+    fr = training.RangeFrames()
+    fr.add_range_image(3, torch.full((8, 40), 7.0), torch.zeros(8, 40), torch.ones(8, 40), g["beam_inclinations"].tolist(), s2w, "Waymo", s2w)
+    pts = fr.inverse_projection_with_range(3, fr.get_depth(3))
+    assert pts.shape == (320, 3) and torch.allclose((pts - s2w[:3, 3]).norm(dim=1), torch.full((320,), 7.0), atol=1e-4)
+
+
 @pytest.mark.gpu
 def test_short_optimisation_run_on_the_gpu():
     """Targets rendered from a ground-truth scene; a perturbed copy is optimised for 60 iterations through
