@@ -83,7 +83,7 @@ struct lrt_state {
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -355,6 +355,7 @@ struct TraceParams {
     // collect & resolve forward
     float slab0; int* err_flag; float* cr_lists;
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
+    float* tile_w0;        // k_fwd_cr4: per tile, the first-slab width learnt in the previous frame (0 = none yet)
     unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
 };
 
@@ -1164,7 +1165,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
@@ -1195,7 +1196,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
     delete st->timers;
     delete st;
@@ -1219,6 +1220,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
@@ -1560,6 +1562,21 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 st->cr_blocks_cap = cap;
             }
             tp.cr_lists = st->cr_lists;
+            tp.tile_w0 = nullptr;
+            if (wg4 && st->learn_slab) {                             // widths are kept while the image size, tiling and default width stay the same
+                const int key[3] = {H * 65536 + W, tp.tw_log2, (int)(st->slab0 * 1000.f)};
+                if (tp.n_tiles > st->tile_w0_n) {
+                    HIPCHK(hipStreamSynchronize(stream));
+                    (void)hipFree(st->tile_w0); st->tile_w0 = nullptr; st->tile_w0_n = 0;
+                    HIPCHK(hipMalloc(&st->tile_w0, (size_t)tp.n_tiles * sizeof(float)));
+                    st->tile_w0_n = tp.n_tiles; st->tile_w0_key[0] = -1;
+                }
+                if (memcmp(key, st->tile_w0_key, sizeof(key)) != 0) {
+                    HIPCHK(hipMemsetAsync(st->tile_w0, 0, (size_t)tp.n_tiles * sizeof(float), stream));
+                    memcpy(st->tile_w0_key, key, sizeof(key));
+                }
+                tp.tile_w0 = st->tile_w0;
+            }
             if (getenv("LRT_DEBUG_OCC")) {
                 int n0 = -1, n1 = -1, n2 = -1;
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<true, 4>, 256, 0);
