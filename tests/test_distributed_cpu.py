@@ -33,7 +33,7 @@ def test_grad_layout_is_one_flat_buffer():
     assert float(lay.flat.sum()) == 10 * 48 * 2.0 + 10 * 3.0
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "auto")])
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "auto"), (2, "auto-dense")])
 def test_sharded_equals_single(tmp_path, world, exchange):
     sc = scenes.make_scene(1500, seed=4, radius_scale=0.2)
     o, d = scenes.kitti_rays(6, 45)
