@@ -201,15 +201,18 @@ def main():
         dom = "backward (k_bwd_prep + radix sort + k_bwd_reduce2)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
         dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic = None; valu = None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(tp)).get(dom, {})
+                traffic = ent.get("hbm_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
+                # supplementary (committed rocprofv3 PMC profile): the trace kernel is bound by VALU issue, not by HBM
+                "valu_issue_frac": valu,
                 "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
                 "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b},
                 "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S}

@@ -78,11 +78,18 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 
     lines.append(f"| `{k}` | {f(fs)} | {f(ws)} | {corr:.1f} | {raw:.1f} | {l2} | {pct('SQ_ACTIVE_INST_ANY')} | {pct('SQ_WAIT_ANY')} | {pct('SQ_WAIT_INST_ANY')} | {f(vi,0)} |")
     if fs is not None or ws is not None:
         traffic[k] = {"hbm_bytes_per_launch": corr * 1e6, "fetch_kb": fs, "write_kb": ws, "raw_bytes_per_launch": raw * 1e6}
+        # share of the chip's VALU issue slots this kernel used: a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles;
+        # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
+        dur = next((float(r["AverageNs"]) * 1e-9 for r in rows if short(r["Name"]) == k), None)
+        if vi and dur:
+            traffic[k]["valu_insts_per_launch"] = vi
+            traffic[k]["valu_issue_frac"] = vi * 4.0 / (dur * 1024 * 2.4e9)
 
 # labels bench.py uses for the dominant (HIP-event timed) region: sums over the kernels of the region
 fw = [traffic[k] for k in traffic if k.startswith("k_fwd_")]
 if fw:
-    traffic["forward (k_fwd_cr4 + k_fwd_colour)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in fw)}
+    traffic["forward (k_fwd_cr4 + k_fwd_colour)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in fw),
+                                                      "valu_issue_frac_dominant_kernel": max((x.get("valu_issue_frac", 0.0) for x in fw), default=None)}
 bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
 if bw:
     traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce2)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
