@@ -80,7 +80,7 @@ struct lrt_state {
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float2* hit_wa; int defer_colour; int fast_valid;
-    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 1 = lane per hit (default), 0 = thread per 16 hits
+    void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 2 = lane per hit + LDS-transposed column sums (default), 1 = lane per hit + DPP segmented scan, 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
@@ -710,6 +710,95 @@ __device__ __forceinline__ float seg_step(float v, int off, bool same, int lane)
     return (same && lane >= off) ? v + y : v;
 }
 
+// Variant of the reduction ("transposed"): the 58 per-hit components go through LDS as a [hit][component] matrix, lane c then
+// walks its column hit by hit and adds; at the end of a run of equal gidx the 58 lanes store the Gaussian's gradient row with ONE
+// store instruction (lane c -> component c).  No 58 x 6 dependent DPP steps and no 58 single-lane stores per run.
+#define R3_STRIDE 59                       // odd row stride: conflict-free when lane = hit writes and when lane = component reads
+__global__ void __launch_bounds__(256) k_bwd_reduce3(const TraceParams p)
+{
+    __shared__ float s_m[4][32 * R3_STRIDE];
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < p.n_hits;
+    const unsigned long long wave0 = i - (unsigned long long)lane;
+    const unsigned long long key = live ? p.sorted_keys[i] : ~0ull;
+    const int g = live ? (int)(key >> p.id_bits) : -1;
+    const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
+    const int nsh = p.nsh;
+    float acc[10], ash[48];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 48; k++) ash[k] = 0.f;
+    if (live) {
+        const unsigned r = id / (unsigned)p.hit_cap;
+        const float4 hp = p.hit_pk[id];
+        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
+        const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
+        const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
+        const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
+        const float op = p.opac[g];
+        const float t = hp.x, da = hp.y, ws = hp.z, w = fabsf(ws);
+        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
+        LrtHitGeom hg;
+        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
+        const float dNgs[3] = {r3_.x * w, r3_.y * w, r3_.z * w};
+        LrtHitGrad gr;
+        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, r0_.w * w, dNgs, &gr);
+        acc[0] = gr.d_mean[0]; acc[1] = gr.d_mean[1]; acc[2] = gr.d_mean[2];
+        acc[3] = gr.d_scale[0]; acc[4] = gr.d_scale[1];
+        acc[5] = gr.d_rot[0]; acc[6] = gr.d_rot[1]; acc[7] = gr.d_rot[2]; acc[8] = gr.d_rot[3];
+        acc[9] = hg.G * da;
+        float b[16];
+        lrt_sh_basis(p.deg, d, b);
+        const float c0 = (ws < 0.f) ? 0.f : r2_.x * w, c1 = r2_.y * w, c2 = r2_.z * w;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nsh) { ash[3 * k] = b[k] * c0; ash[3 * k + 1] = b[k] * c1; ash[3 * k + 2] = b[k] * c2; }
+    }
+    const int wv = threadIdx.x >> 6;
+    float* m = s_m[wv];
+    const int gn = __shfl_down(g, 1);
+    const bool tail = live && (lane == 63 || gn != g);
+    const unsigned long long tails = __ballot(tail);
+    if (!tails) return;
+    // does the first / last run of this wave continue in a neighbouring wave?  (then its total is added atomically)
+    const int g_first = __builtin_amdgcn_readlane(g, 0), g_last = __builtin_amdgcn_readlane(g, 63);
+    bool sh_first = false, sh_last = false;
+    if (wave0 > 0) sh_first = ((int)(p.sorted_keys[wave0 - 1] >> p.id_bits) == g_first);
+    if (wave0 + 64 < p.n_hits) sh_last = ((int)(p.sorted_keys[wave0 + 64] >> p.id_bits) == g_last);
+    const int nc = 10 + 3 * nsh;                               // live components
+    const int M3 = p.M * 3;
+    float run = 0.f;
+    for (int half = 0; half < 2; half++) {
+        if ((lane >> 5) == half) {                               // lanes of this half publish their hit's components
+            float* row = m + (lane & 31) * R3_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 10; k++) row[k] = acc[k];
+#pragma unroll
+            for (int k = 0; k < 48; k++) if (k < 3 * nsh) row[10 + k] = ash[k];
+        }
+        // wave-local LDS: in-order, no barrier needed inside a wave
+        for (int j = 0; j < 32; j++) {
+            const int hj = 32 * half + j;
+            if (lane < nc) run += m[j * R3_STRIDE + lane];
+            if ((tails >> hj) & 1ull) {
+                const int gj = __builtin_amdgcn_readlane(g, hj);
+                const bool shared = ((gj == g_first) && sh_first) || (hj == 63 && sh_last);
+                if (lane < nc) {
+                    float* dst = lane < 3 ? p.d_means + 3 * (size_t)gj + lane
+                               : lane < 5 ? p.d_scales + 2 * (size_t)gj + (lane - 3)
+                               : lane < 9 ? p.d_rots + 4 * (size_t)gj + (lane - 5)
+                               : lane == 9 ? p.d_opac + gj
+                               : p.d_shs + (size_t)gj * M3 + (lane - 10);
+                    if (shared) unsafeAtomicAdd(dst, run); else *dst = run;
+                }
+                run = 0.f;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1165,7 +1254,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 1; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
@@ -1232,7 +1321,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
     if (!strcmp(name, "defer_colour")) { st->defer_colour = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
-    if (!strcmp(name, "reduce_mode")) { st->reduce_mode = value ? 1 : 0; return LRT_OK; }
+    if (!strcmp(name, "reduce_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: reduce_mode must be 0, 1 or 2"); st->reduce_mode = value; return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
         if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
@@ -1689,6 +1778,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     if (st->reduce_mode == 0) {
                         const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
                         hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
+                    } else if (st->reduce_mode == 2) {
+                        hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                     } else {
                         hipLaunchKernelGGL(k_bwd_reduce2, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                     }

@@ -27,7 +27,8 @@ MODES = [{"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 1, "bwd
          {"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
          {"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 1},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8}]
+         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8},
+         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "reduce_mode": 1}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "reduce_mode": 0}]
 GRADS = ("means", "scales", "rotations", "opacities", "shs")
 
 
@@ -47,7 +48,7 @@ def s10k():
     return sc, o, d, dL
 
 
-@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else ""))
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else "") + (f"-red{m['reduce_mode']}" if "reduce_mode" in m else ""))
 @pytest.mark.parametrize("deg,bg", [(3, (0, 0, 1)), (0, (0, 0, 0)), (1, (0.3, 0.7, 0.2)), (2, (0, 0, 1))])
 def test_s10k_forward_backward_match_oracle(s10k, mode, deg, bg):
     sc, o, d, dL = s10k
