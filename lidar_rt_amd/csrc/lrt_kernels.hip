@@ -1765,7 +1765,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
                     tp.fast_prep = st->fast_valid;
-                    if (tp.fast_prep) hipLaunchKernelGGL(k_bwd_prep<true>, dim3(blocks), dim3(64), 0, stream, tp);
+                    if (tp.fast_prep) { hipLaunchKernelGGL(k_bwd_prep<true>, dim3(blocks), dim3(64), 0, stream, tp); st->fast_valid = 0; }   // hit_pk's colours are now overwritten: a second backward recomputes them
                     else hipLaunchKernelGGL(k_bwd_prep<false>, dim3(blocks), dim3(64), 0, stream, tp);
                 }
                 if (n_hits > 0) {

@@ -288,6 +288,31 @@ def test_randomised_scenes_cr4_against_the_legacy_packet_kernel(seed):
         assert rel_l2(a["grads"][k], b["grads"][k]) < 5e-3 and frac_outside(a["grads"][k], b["grads"][k], 1e-3) <= 2e-2, k
 
 
+def test_backward_twice_through_one_forward(s10k):
+    """retain_graph: the second backward finds the recorded colours overwritten by the first one and must recompute
+    them without changing the result."""
+    sc, o, d, dL = s10k
+    for place in (0,):
+        tr = Tracer()
+        for k, v in {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "reduce_mode": 2, "hit_cap": 256}.items():
+            tr.optix_context.set_option(k, v)
+        t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in sc.items()}
+        ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")
+        from tests.hip_util import settings
+        tr.build_from_gaussians(t["means"], t["scales"], t["rotations"], t["opacities"])
+        out, _ = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"],
+                    scales=t["scales"], rotations=t["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+        g = torch.as_tensor(dL, device="cuda:0")
+        grads = []
+        for rep in range(3):
+            for v in t.values():
+                v.grad = None
+            out.backward(g, retain_graph=True)
+            grads.append({k: v.grad.detach().cpu().numpy().copy() for k, v in t.items()})
+        for k in GRADS:
+            assert rel_l2(grads[1][k], grads[0][k]) < 1e-5 and rel_l2(grads[2][k], grads[0][k]) < 1e-5, (place, k)
+
+
 def test_two_forwards_before_backward(s10k):
     """The hit record belongs to the LAST forward; the backward of an earlier forward must notice and re-trace."""
     from lidar_rt_amd.diff_lidar_tracer import Tracer
