@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include <vector>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -292,9 +293,10 @@ __global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __res
     for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(j * 8); nd[49] = __int_as_float(1); }   // children = leaves, base leaf 8j
     float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
-    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], lo[1], lo[2], hi[0]);
+    // AoS child = (lo.x hi.x lo.y hi.y | lo.z hi.z ptr flags): each axis' two planes are one operand pair of v_pk_fma_f32
+    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], hi[0], lo[1], hi[1]);
     na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
-                  : make_float4(hi[1], hi[2], __int_as_float(leaf), __int_as_float(1));       // flags: 1 = leaf, 2 = empty
+                  : make_float4(lo[2], hi[2], __int_as_float(leaf), __int_as_float(1));       // flags: 1 = leaf, 2 = empty
 }
 
 // Level-l nodes (l >= 2): child c of node j is node 8j+c of level l-1.
@@ -316,9 +318,9 @@ __device__ __forceinline__ void upper_child(int tid, int n_nodes, int node_off, 
     for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
     if (c == 0) { nd[48] = __int_as_float(child_off + j * 8); nd[49] = __int_as_float(0); }
     float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
-    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], lo[1], lo[2], hi[0]);
+    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], hi[0], lo[1], hi[1]);
     na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
-                  : make_float4(hi[1], hi[2], __int_as_float(child_off + ch), __int_as_float(0));
+                  : make_float4(lo[2], hi[2], __int_as_float(child_off + ch), __int_as_float(0));
 }
 
 __global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* nodes, float* nodes_aos)
@@ -1625,7 +1627,8 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
     }
     if (st->fwd_mode == 1 || st->fwd_mode == 2) {
-        const bool wg4 = st->fwd_mode == 2;                          // one workgroup of 4 waves per 16-ray tile (k_fwd_cr4)
+        const bool wg4 = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26);   // one workgroup of 4 waves per 16-ray tile (k_fwd_cr4,
+                                                                     // 32-bit byte offsets into the leaf records); k_fwd_cr beyond
         const int tile_rays = wg4 ? C4_RAYS : CR_RAYS;
         const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
         tp.tw_log2 = st->tile16_w_log2;

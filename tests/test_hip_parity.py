@@ -280,7 +280,9 @@ def test_randomised_scenes_cr4_against_the_legacy_packet_kernel(seed):
             "hit_cap": int(r.choice([16, 64, 256]))}
     a = run_hip(sc, o, d, deg, scenes.BG_DEFAULT, dL, opts=opts)
     b = run_hip(sc, o, d, deg, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 0, "bwd_mode": 0})
-    assert rel_l2(a["out"], b["out"]) < 5e-5 and frac_outside(a["out"], b["out"], 1e-4) <= 2e-3
+    # the two kernels evaluate the ray/quad intersection with differently contracted FMAs (packed fp32 in k_fwd_cr4): ulps in
+    # alpha flip a 1/255 or 0.99 threshold for an isolated hit now and then; one such flip in a small image is ~1e-4 in L2
+    assert rel_l2(a["out"], b["out"]) < 5e-4 and frac_outside(a["out"], b["out"], 1e-4) <= 2e-3
     # a hit whose alpha or transmittance sits on a threshold is composited by one implementation and not by the other (1-ulp
     # differences in t): single weights differ, so the per-Gaussian quantities are compared statistically
     assert rel_l2(a["accum"], b["accum"]) < 2e-3 and frac_outside(a["accum"], b["accum"], 1e-3) <= 1e-2
