@@ -64,7 +64,7 @@ struct lrt_state {
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
-    float* nodes; float* nodes_aos; size_t cap_nodes;
+    float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
     int bounds_sel;
     unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
@@ -202,7 +202,8 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
 
 __global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
                          const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals,
-                         const float* __restrict__ scales, unsigned* __restrict__ cone)
+                         const float* __restrict__ scales, unsigned* __restrict__ cone, const float* __restrict__ rots,
+                         float4* __restrict__ pack)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
@@ -245,13 +246,19 @@ __global__ void k_morton(int P, const float* __restrict__ means, const float* __
         key = lrt_morton63(cx, cy, cz);
     }
     keys[g] = key; vals[g] = (uint32_t)g;
+    if (pack) {   // the parameters of one primitive in one 64-byte line: k_make_records gathers them by sorted index, and a
+                  // gather from four separate arrays (12/8/16/4 bytes each) costs four sectors per primitive
+        pack[4 * (size_t)g] = make_float4(x, y, z, opac[g]);
+        pack[4 * (size_t)g + 1] = make_float4(scales[2 * g], scales[2 * g + 1], rots[4 * g], rots[4 * g + 1]);
+        pack[4 * (size_t)g + 2] = make_float4(rots[4 * g + 2], rots[4 * g + 3], 0.f, 0.f);
+    }
 }
 
 // One thread per sorted slot: quad record + AABB from the raw Gaussian (fused build2DRectangle).
 __global__ void k_make_records(int P, const uint32_t* __restrict__ order, const float* __restrict__ means,
                                const float* __restrict__ scales, const float* __restrict__ rots,
                                const float* __restrict__ opac, float mod, float* __restrict__ rec,
-                               float* __restrict__ aabb)
+                               float* __restrict__ aabb, const float4* __restrict__ pack)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ppad = (P + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
@@ -263,11 +270,17 @@ __global__ void k_make_records(int P, const uint32_t* __restrict__ order, const 
         return;
     }
     int g = (int)order[k];
-    float mu[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-    float sc[2] = {scales[2 * g], scales[2 * g + 1]};
-    float q[4] = {rots[4 * g], rots[4 * g + 1], rots[4 * g + 2], rots[4 * g + 3]};
+    float mu[3], sc[2], q[4], op;
+    if (pack) {
+        const float4 a = pack[4 * (size_t)g], b = pack[4 * (size_t)g + 1], c = pack[4 * (size_t)g + 2];
+        mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; op = a.w; sc[0] = b.x; sc[1] = b.y; q[0] = b.z; q[1] = b.w; q[2] = c.x; q[3] = c.y;
+    } else {
+        mu[0] = means[3 * g]; mu[1] = means[3 * g + 1]; mu[2] = means[3 * g + 2]; op = opac[g];
+        sc[0] = scales[2 * g]; sc[1] = scales[2 * g + 1];
+        q[0] = rots[4 * g]; q[1] = rots[4 * g + 1]; q[2] = rots[4 * g + 2]; q[3] = rots[4 * g + 3];
+    }
     float r[LRT_REC_FLOATS]; LrtSplatAux aux;
-    lrt_make_splat(mu, sc, q, opac[g], mod, g, r, &aux);
+    lrt_make_splat(mu, sc, q, op, mod, g, r, &aux);
     float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
     dst[0] = make_float4(r[0], r[1], r[2], r[3]);   dst[1] = make_float4(r[4], r[5], r[6], r[7]);
     dst[2] = make_float4(r[8], r[9], r[10], r[11]); dst[3] = make_float4(r[12], r[13], r[14], r[15]);
@@ -1195,13 +1208,14 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack};
     for (void* q : olds) (void)hipFree(q);
-    st->nodes_aos = nullptr;
+    st->nodes_aos = nullptr; st->pack = nullptr;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc(&st->aabb, cap * 6 * sizeof(float)));
+    HIPCHK(hipMalloc(&st->pack, cap * 4 * sizeof(float4)));
     HIPCHK(hipMalloc(&st->keys_a, cap * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&st->keys_b, cap * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&st->vals_a, cap * sizeof(uint32_t)));
@@ -1281,7 +1295,7 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
     if (st->cone_host) (void)hipHostFree(st->cone_host);
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1311,6 +1325,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
@@ -1491,7 +1506,8 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         st->bounds_sel ^= 1;
         int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
         hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)cone);
-        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone);
+        float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
+        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone, rots, pack);
         if (cone) {                                              // the sort and the tree are sized by the kept count: one 4-byte read-back
             HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
@@ -1505,7 +1521,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
             int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
-            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb);
+            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack);
         }
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
