@@ -261,6 +261,30 @@ def test_queue_overflow_falls_back_to_narrower_slabs(s10k):
         assert rel_l2(b["grads"][k], a["grads"][k]) < 1e-5, k
 
 
+def test_coincident_gaussians_are_ordered_by_index():
+    """Every Gaussian twice (same geometry, other opacity and SH): each ray gets pairs of hits with bit-identical t.  The rank
+    sort of k_fwd_cr4 sees them as a rank total below n(n-1)/2 and adds the gidx tie-break in a second pass; the result must
+    be the (t, gidx) order of the one-wave kernel, whatever the waves per tile and the order of collection."""
+    base = scenes.make_scene(1500, seed=11, radius_scale=0.3)
+    r = np.random.default_rng(12)
+    sc = {k: np.concatenate([v, v], 0) for k, v in base.items()}
+    n = base["means"].shape[0]
+    sc["opacities"][n:] = np.clip(r.uniform(0.05, 0.9, (n, 1)), 0.01, 0.99).astype(np.float32)
+    sc["shs"][n:] = (0.5 * r.normal(size=base["shs"].shape)).astype(np.float32)
+    perm = r.permutation(2 * n)                                                # the two copies far apart in index
+    sc = {k: np.ascontiguousarray(v[perm]) for k, v in sc.items()}
+    o, d = scenes.kitti_rays(8, 96)
+    dL = scenes.upstream_grad(8, 96, seed=3)
+    ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 1, "bwd_mode": 2})
+    for nw in (4, 8):
+        a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw})
+        b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw, "slab0_mm": 3000})
+        assert rel_l2(a["out"], b["out"]) < 1e-6, nw                           # other slabs, other collection order: same image
+        assert rel_l2(a["out"], ref["out"]) < 5e-4 and frac_outside(a["out"], ref["out"], 1e-4) <= 5e-3, nw
+        for k in GRADS:
+            assert rel_l2(a["grads"][k], ref["grads"][k]) < 5e-3, (nw, k)
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103, 104])
 def test_randomised_scenes_cr4_against_the_legacy_packet_kernel(seed):
     """Two independent implementations (k_fwd_cr4 + sorted-reduction backward vs the K-buffer packet kernel + re-trace
