@@ -198,7 +198,7 @@ def main():
         bf, bb = algorithmic_bytes(C, K, deg)
         ms_f = kt["fwd"][0] / max(kt["fwd"][1], 1); ms_b = kt["bwd"][0] / max(kt["bwd"][1], 1)
         ms_build = kt["build"][0] / max(kt["build"][1], 1)
-        dom = "backward (k_bwd_prep + radix sort + k_bwd_reduce2)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
+        dom = "backward (k_bwd_prep + radix sort + k_bwd_reduce3)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
         dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None; valu = None

@@ -92,7 +92,7 @@ if fw:
                                                       "valu_issue_frac_dominant_kernel": max((x.get("valu_issue_frac", 0.0) for x in fw), default=None)}
 bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
 if bw:
-    traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce2)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
+    traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce3)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
