@@ -118,6 +118,9 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
 
 /* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays). */
 int lrt_set_option(lrt_state* st, const char* name, int value);
+/* Current value of an option (hit_cap, hit_cap_auto, fwd_mode, bwd_mode, reduce_mode, defer_colour, c4_waves): hit_cap can grow
+ * by itself, see lrt_kernels.hip. */
+int lrt_get_option(lrt_state* st, const char* name, int* value);
 
 /* Sparse gradient exchange of the azimuth-sharded backward (lidar_rt_amd/parallel.py; not in the reference, which is
  * single-GPU).  Row r of `rows` (n x (11 + 3M) floats) holds, for Gaussian idx[r]:

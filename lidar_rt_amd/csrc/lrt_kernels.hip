@@ -79,7 +79,7 @@ struct lrt_state {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     unsigned* ctrl;      // 16 words zeroed by ONE memset per forward: [0..7] tile queues, [8] hit_ovf, [9] hit_count, [10] err_flag, [11] ovf_count
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
-    size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled;
+    size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled; int hit_cap_auto; int key_avg, key_avg_alloc;   // key_avg: dense (gidx, id) key list sized for this many composited hits per ray
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float2* hit_wa; int defer_colour; int fast_valid;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 2 = lane per hit + LDS-transposed column sums (default), 1 = lane per hit + DPP segmented scan, 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
@@ -1270,7 +1270,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
@@ -1307,6 +1307,15 @@ void lrt_destroy(lrt_state* st)
     delete st;
 }
 
+int lrt_get_option(lrt_state* st, const char* name, int* value)
+{
+    if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
+    const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
+        {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}};
+    for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
+    LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: unknown option '%s'", name);
+}
+
 int lrt_set_option(lrt_state* st, const char* name, int value)
 {
     if (!st || !name) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: null argument");
@@ -1322,6 +1331,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         if (value < 1 || value > 65536) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: hit_cap out of range");
         st->hit_cap = value; st->hits_valid = 0; return LRT_OK;
     }
+    if (!strcmp(name, "hit_cap_auto")) { st->hit_cap_auto = value ? 1 : 0; return LRT_OK; }   // 1 (default): the record capacity doubles after an overflow
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
@@ -1468,6 +1478,9 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
         case 2: src = st->nodes; bytes = (long long)st->n_nodes * LRT_NODE_FLOATS * 4; break;
         case 3: src = st->aabb; bytes = (long long)st->P_built * 6 * 4; break;
         case 4: src = st->dbg; bytes = (long long)st->dbg_floats * 4; break;
+        case 5: src = st->hit_n; bytes = (long long)st->hit_rays_cap * 4; break;                          // composited hits per ray of the last recording forward
+        case 6: src = st->hit_t; bytes = (long long)st->hit_rays_cap * st->hit_cap_alloc * 4; break;      // their depths, [ray][hit_cap]
+        case 7: src = st->hit_g; bytes = (long long)st->hit_rays_cap * st->hit_cap_alloc * 4; break;      // their Gaussians
         default: LRT_FAIL(LRT_ERR_ARG, "lrt_debug_read: unknown buffer %d", which);
     }
     long long n = bytes < max_bytes ? bytes : max_bytes;
@@ -1609,7 +1622,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     const bool defer = (st->fwd_mode == 1 || st->fwd_mode == 2) && st->defer_colour;                 // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
-        if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc) {
+        if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc || st->key_avg > st->key_avg_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
             void* olds[] = {st->hit_t, st->hit_g, st->hit_n, st->hit_keys, st->hit_keys_sorted, st->hit_pk, st->ray_pk, st->bsort_tmp, st->hit_off, st->scan_tmp, st->hit_wa};
             for (void* q : olds) (void)hipFree(q);
@@ -1626,7 +1639,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             HIPCHK(hipMalloc(&st->hit_off, (HW + 1) * sizeof(unsigned)));
             { size_t sb = 0; HIPCHK(rocprim::exclusive_scan(nullptr, sb, (unsigned*)st->hit_n, st->hit_off, 0u, HW, rocprim::plus<unsigned>(), stream));
               st->scan_tmp_bytes = sb + 256; HIPCHK(hipMalloc(&st->scan_tmp, st->scan_tmp_bytes)); }
-            const size_t kc = HW * (size_t)(st->hit_cap < 64 ? st->hit_cap : 64);     // dense key list: 64 hits/ray on average
+            const size_t kc = HW * (size_t)(st->hit_cap < st->key_avg ? st->hit_cap : st->key_avg);     // dense key list: 64 hits/ray on average to start with
             HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
             HIPCHK(hipMalloc(&st->hit_keys_sorted, kc * sizeof(unsigned long long)));
             size_t tmpb = 0;
@@ -1634,7 +1647,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             st->bsort_tmp_bytes = tmpb + 256;
             HIPCHK(hipMalloc(&st->bsort_tmp, st->bsort_tmp_bytes));
             st->key_cap = (unsigned)(kc < 0xffffffffull ? kc : 0xffffffffull);
-            st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap;
+            st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap; st->key_avg_alloc = st->key_avg;
         }
         tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_ovf = st->hit_ovf;
         tp.hit_cap = st->hit_cap; tp.hw = (int)HW; tp.hit_wa = st->hit_wa; tp.hit_pk = st->hit_pk;
@@ -1769,6 +1782,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
             tp.hw = H * W;
             const bool sorted = (st->bwd_mode == 2) && st->hit_keys && n_hits <= st->key_cap;
+            if (st->bwd_mode == 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;   // this frame: atomics; next: a longer key list
             if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
                 hipLaunchKernelGGL(k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
@@ -1807,6 +1821,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             HIPCHK(hipGetLastError());
             return LRT_OK;
         }
+        // a ray composited more hits than the record holds: this frame is re-traced (an order of magnitude slower), the
+        // following ones record with twice the capacity
+        if (st->hit_cap_auto && st->hit_cap < 4096 && (size_t)H * W * (size_t)st->hit_cap * 2 < (1ull << 32)) st->hit_cap *= 2;
     }
     return launch_trace(st, tp, true, stream);   // no (complete) record: re-trace like the reference
 }

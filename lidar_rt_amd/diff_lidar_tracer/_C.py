@@ -69,6 +69,15 @@ class OptiXStateWrapper:
         for h in self._handles.values():
             _capi.check(self._lib.lrt_set_option(h, name.encode(), int(value)), "lrt_set_option")
 
+    def get_option(self, name: str, device=None) -> int:
+        """Current value of an option on `device` (hit_cap may have grown after an overflow of the hit record)."""
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _, h = self.handle(device)
+        v = C.c_int(0)
+        _capi.check(self._lib.lrt_get_option(h, name.encode(), C.byref(v)), "lrt_get_option")
+        return int(v.value)
+
     def check(self, device=None, wait: bool = True):
         """Raise if the most recent forward on `device` reported an internal overflow (waits for it when `wait`)."""
         for idx, h in self._handles.items():

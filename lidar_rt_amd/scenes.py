@@ -185,3 +185,16 @@ def s1m():
 
 
 BG_DEFAULT = np.array([0.0, 0.0, 1.0], np.float32)  # train.py:104-106
+
+
+def dense_translucent(P: int = 25000, seed: int = 21, H: int = 4, W: int = 48):
+    """Stress scene: a 5 m world of large Gaussians (3x the usual scales) of opacity 0.03 -- about 130 candidate and 100
+    composited hits per ray, up to ~600 / ~500 -- with everything that could come within 0.3 m of the sensor removed (hits
+    nearer than 0.2 m are outside the parity contract).  Returns (scene, ray_o, ray_d)."""
+    sc = make_scene(P, seed=seed, radius_scale=0.1)
+    sc["opacities"][:] = 0.03
+    sc["scales"] *= 3.0
+    o, d = kitti_rays(H, W)
+    reach = 0.3 + 2.1 * 1.4143 * sc["scales"].max(1)              # half diagonal of the quad at opacity 0.03 (2.02 sigma)
+    keep = np.linalg.norm(sc["means"] - o.reshape(-1, 3)[0], axis=1) > reach
+    return {k: np.ascontiguousarray(v[keep]) for k, v in sc.items()}, o, d
