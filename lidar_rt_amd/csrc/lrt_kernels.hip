@@ -68,6 +68,9 @@ struct lrt_state {
     unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
     int bounds_sel;
     unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
+    // speculative sizing of the culled build: the sort and the tree are sized from the PREVIOUS culled build's kept count
+    // (x1.25 + 4096), so that no read-back stalls the launch queue; cone_host = [kept, overflow] of the last build, valid after cone_ev
+    hipEvent_t cone_ev; int cone_pending, cone_have_prev, cone_prev_P, spec_cull, cull_guess; unsigned cone_prev; int cone_flag_live;
     unsigned* tile_counter;
     unsigned long long* stats;   // 8 counters
     int stats_enabled;
@@ -105,12 +108,12 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v) { for (int o = 32; o 
 // Ray-cone culling for builds that serve only a subset of the frame's rays (one rank's azimuth slab): Gaussians whose
 // bounding sphere lies outside the cone around the rays cannot be hit and are left out of the LBVH.
 // cone words: [0..2] sum of unit directions (float), [3..5] / [6..8] min / max origin (ordered uint), [9] min cos(angle to the
-// axis) (ordered uint), [10] kept primitives (uint).
+// axis) (ordered uint), [10] kept primitives (uint), [11] set when the kept primitives did not fit the speculative size.
 __global__ void k_cone_init(unsigned* cone)
 {
     const int i = threadIdx.x;
     if (i < 3) cone[i] = 0u; else if (i < 6) cone[i] = 0xffffffffu; else if (i < 9) cone[i] = 0u;
-    else if (i == 9) cone[i] = 0xffffffffu; else if (i == 10) cone[i] = 0u;
+    else if (i == 9) cone[i] = 0xffffffffu; else if (i == 10 || i == 11) cone[i] = 0u;
 }
 
 __global__ void __launch_bounds__(256) k_cone_axis(int n, const float* __restrict__ ro, const float* __restrict__ rd, unsigned* cone)
@@ -200,38 +203,63 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
     }
 }
 
-__global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
-                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals,
-                         const float* __restrict__ scales, unsigned* __restrict__ cone, const float* __restrict__ rots,
-                         float4* __restrict__ pack)
+// Morton keys of a ray-cone culled build: the kept primitives are compacted to the front of the key / index lists (their
+// order is fixed by the sort afterwards).  One workgroup takes 2048 consecutive primitives and ONE slot range from the global
+// counter (a returning atomic per wave on one address serialises in L2: 15.6 k of them cost ~0.25 ms at 1 M primitives).
+#define MC_ITEMS 8
+__global__ void __launch_bounds__(256) k_morton_cull(int P, const float* __restrict__ means, const float* __restrict__ opac,
+                                                     const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys,
+                                                     uint32_t* vals, const float* __restrict__ scales, unsigned* __restrict__ cone, unsigned keep_cap)
 {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
-    if (cone) {
-        // culled build: the kept primitives are compacted (one atomic per wave); their order is fixed by the sort afterwards
-        bool keep = false;
+    __shared__ unsigned s_cnt[MC_ITEMS * 4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == 0 && tid < 6) bounds_next[tid] = tid < 3 ? 0xffffffffu : 0u;   // the other bounds set, for the next build
+    float lo[3], ext = 0.f;
+    for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
+    const float sc_ = ext > 0.f ? 2097151.0f / ext : 0.f;
+    uint64_t key[MC_ITEMS]; unsigned within[MC_ITEMS]; unsigned keepmask = 0u;
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; it++) {
+        const int g = (blockIdx.x * MC_ITEMS + it) * 256 + tid;
+        bool keep = false; key[it] = 0;
         if (g < P) {
             const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
             keep = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f &&
                    !cone_culls(cone, x, y, z, quad_half_diag(scales, opac, g));
+            if (keep) {
+                const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo[0]) * sc_, 0.f), 2097151.f);
+                const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo[1]) * sc_, 0.f), 2097151.f);
+                const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo[2]) * sc_, 0.f), 2097151.f);
+                key[it] = lrt_morton63(cx, cy, cz);
+            }
         }
         const unsigned long long m = __ballot(keep);
-        if (!m) return;
-        const int lane = threadIdx.x & 63;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(cone + 10, (unsigned)__popcll(m));
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (!keep) return;
-        const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        float lo[3], ext = 0.f;
-        for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
-        const float sc_ = ext > 0.f ? 2097151.0f / ext : 0.f;
-        const uint32_t cx = (uint32_t)fminf(fmaxf((means[3 * g] - lo[0]) * sc_, 0.f), 2097151.f);
-        const uint32_t cy = (uint32_t)fminf(fmaxf((means[3 * g + 1] - lo[1]) * sc_, 0.f), 2097151.f);
-        const uint32_t cz = (uint32_t)fminf(fmaxf((means[3 * g + 2] - lo[2]) * sc_, 0.f), 2097151.f);
-        keys[slot] = lrt_morton63(cx, cy, cz); vals[slot] = (uint32_t)g;
-        return;
+        within[it] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[it * 4 + wv] = (unsigned)__popcll(m);
+        keepmask |= keep ? (1u << it) : 0u;
     }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tot = 0u;
+        for (int i = 0; i < MC_ITEMS * 4; i++) { const unsigned c = s_cnt[i]; s_cnt[i] = tot; tot += c; }   // exclusive prefix in place
+        s_base = tot ? atomicAdd(cone + 10, tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; it++) {
+        if (!((keepmask >> it) & 1u)) continue;
+        const unsigned slot = s_base + s_cnt[it * 4 + wv] + within[it];
+        if (slot >= keep_cap) { atomicOr(cone + 11, 1u); continue; }   // speculative size exceeded: reported by the next forward
+        keys[slot] = key[it]; vals[slot] = (uint32_t)((blockIdx.x * MC_ITEMS + it) * 256 + tid);
+    }
+}
+
+__global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
+                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals,
+                         const float* __restrict__ scales, const float* __restrict__ rots, float4* __restrict__ pack)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
     if (g >= P) return;
     float lo[3], ext = 0.f;
     for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
@@ -258,12 +286,14 @@ __global__ void k_morton(int P, const float* __restrict__ means, const float* __
 __global__ void k_make_records(int P, const uint32_t* __restrict__ order, const float* __restrict__ means,
                                const float* __restrict__ scales, const float* __restrict__ rots,
                                const float* __restrict__ opac, float mod, float* __restrict__ rec,
-                               float* __restrict__ aabb, const float4* __restrict__ pack)
+                               float* __restrict__ aabb, const float4* __restrict__ pack, const unsigned* __restrict__ kept_ptr)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ppad = (P + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
     if (k >= Ppad) return;
-    if (k >= P) {                                   // padding so that every leaf holds LRT_LEAF records
+    const int kept = kept_ptr ? min((int)*kept_ptr, P) : P;      // speculatively sized culled build: slots [kept, P) hold sentinel keys
+    if (k >= kept) {                                // padding so that every leaf holds LRT_LEAF records
+        if (k < P) { float* a = aabb + (size_t)k * 6; a[0] = a[1] = a[2] = 1e30f; a[3] = a[4] = a[5] = -1e30f; }
         float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
         dst[0] = make_float4(0.f, 0.f, 1.f, -1.f); dst[1] = make_float4(0.f, 0.f, 0.f, -1.f);
         dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1166,10 +1196,10 @@ __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 
 // The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
 __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
-                                                  unsigned* __restrict__ ctrl)
+                                                  unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (i < 16) ctrl[i] = 0u;
+    if (i < 16) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;     // [10] err_flag: 8 = the culled build lost primitives
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
         for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1270,7 +1300,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
     if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
@@ -1296,7 +1326,7 @@ void lrt_destroy(lrt_state* st)
     if (!st) return;
     DeviceGuard dg(st->device);
     void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
-    if (st->cone_host) (void)hipHostFree(st->cone_host);
+    if (st->cone_host) { (void)hipHostFree(st->cone_host); (void)hipEventDestroy(st->cone_ev); }
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
@@ -1335,6 +1365,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
+    if (!strcmp(name, "cull_guess")) { st->cull_guess = value; return LRT_OK; }   // test hook: speculative size of the NEXT culled build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
@@ -1365,7 +1397,12 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
 /* Serial number of the most recent lrt_forward on this state (the hit record belongs to that forward). */
 long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
 
-int lrt_built_count(lrt_state* st) { return (st && st->P >= 0) ? st->P_built : -1; }
+int lrt_built_count(lrt_state* st)
+{
+    if (!st || st->P < 0) return -1;
+    if (st->cone_pending && hipEventSynchronize(st->cone_ev) == hipSuccess) return (int)(st->cone_host[0] < (unsigned)st->P_built ? st->cone_host[0] : (unsigned)st->P_built);
+    return st->P_built;
+}
 
 static int grad_rows(const char* fn, bool gather, int device, int P, int M, int n, const int32_t* idx, float* rows, float* d_means,
                      float* d_scales, float* d_rots, float* d_opac, float* d_shs, float* accum, void* stream_)
@@ -1412,8 +1449,9 @@ int lrt_check_forward(lrt_state* st, int wait)
     const int code = st->hit_ovf_host[2];
     if (code != 0)
         LRT_FAIL(LRT_ERR_STATE, "the last forward trace reported an internal overflow and its output is incomplete [code %d: 1 = more than 256 "
-                 "candidate quads within 0.1 mm along one ray, 2 = BVH queue/stack, 4 = colour overflow list (raise the hit_cap option)]; "
-                 "use option fwd_mode=0", code);
+                 "candidate quads within 0.1 mm along one ray, 2 = BVH queue/stack, 4 = colour overflow list (raise the hit_cap option), 8 = the "
+                 "speculatively sized ray-culled build lost primitives (the next build reads its size back; option spec_cull=0 disables)]; "
+                 "for 1/2 use option fwd_mode=0", code);
     return LRT_OK;
 }
 
@@ -1500,15 +1538,24 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_capacity(st, P, stream);
     if (rc) return rc;
-    st->P = -1;
+    st->P = -1; st->cone_flag_live = 0;
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     int Pk = P;                                                  // primitives that enter the LBVH
     if (P > 0) {
         unsigned* cone = nullptr;
         if (n_rays > 0) {                                        // cull against the cone around the given rays
-            if (!st->cone) { HIPCHK(hipMalloc(&st->cone, 16 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, sizeof(unsigned))); }
+            if (!st->cone) {
+                HIPCHK(hipMalloc(&st->cone, 16 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
+                HIPCHK(hipEventCreateWithFlags(&st->cone_ev, hipEventDisableTiming));
+            }
             cone = st->cone;
+            if (st->cone_pending) {                              // kept count of the previous (speculatively sized) culled build
+                HIPCHK(hipEventSynchronize(st->cone_ev));        // copied right after its k_morton: long done
+                st->cone_pending = 0;
+                st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
+                st->cone_prev = st->cone_host[0];
+            }
             int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
             hipLaunchKernelGGL(k_cone_init, dim3(1), dim3(64), 0, stream, cone);
             hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
@@ -1520,13 +1567,36 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
         hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)cone);
         float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
-        hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone, rots, pack);
-        if (cone) {                                              // the sort and the tree are sized by the kept count: one 4-byte read-back
-            HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            Pk = (int)*st->cone_host;
-            if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
+        // The sort and the tree of a culled build are sized by the kept count.  Reading it back stalls the launch queue (the
+        // host cannot run ahead), so from the second culled build of the same P on the size is SPECULATIVE: 1.25 x the previous
+        // count + 4096; the unused tail holds sentinel keys (sorted last, turned into padding by k_make_records) and the actual count
+        // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
+        unsigned keep_cap = (unsigned)P;
+        bool spec = false;
+        if (cone && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
+            unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess
+                                                        : (st->cone_prev + st->cone_prev / 4 + 4096ull);
+            if (gsz < (unsigned long long)P) { keep_cap = (unsigned)(gsz < 64 ? 64 : gsz); spec = true; }
+            st->cull_guess = 0;
         }
+        if (spec) HIPCHK(hipMemsetAsync(st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
+        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone, keep_cap);
+        else hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, rots, pack);
+        if (cone) {
+            HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            st->cone_prev_P = P;
+            if (spec) {
+                HIPCHK(hipEventRecord(st->cone_ev, stream));
+                st->cone_pending = 1;
+                Pk = (int)keep_cap;
+            } else {                                             // first culled build of this size: one 8-byte read-back
+                HIPCHK(hipStreamSynchronize(stream));
+                Pk = (int)st->cone_host[0];
+                if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
+                st->cone_prev = (unsigned)Pk; st->cone_have_prev = 1;
+            }
+        }
+        st->cone_flag_live = spec ? 1 : 0;
         if (Pk > 0) {
             size_t tmp = st->sort_tmp_bytes;
             // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
@@ -1534,7 +1604,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
             int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
-            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack);
+            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack, (const unsigned*)(spec ? cone + 10 : nullptr));
         }
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
@@ -1611,7 +1681,8 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_fwd_init, dim3(blocks), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl);
+        hipLaunchKernelGGL(k_fwd_init, dim3(blocks), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
+                           (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr));
     }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
@@ -1773,7 +1844,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list (more than 256 candidate quads within 0.1 mm along one ray), 2 = BVH stack, 4 = colour overflow list (> 2^20 composited hits beyond hit_cap; raise the hit_cap option)]; use option fwd_mode=0", st->hit_ovf_host[2]);
+        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list (more than 256 candidate quads within 0.1 mm along one ray), 2 = BVH stack, 4 = colour overflow list (> 2^20 composited hits beyond hit_cap; raise the hit_cap option), 8 = the speculatively sized ray-culled build lost primitives (the next build reads its size back)]; for 1/2 use option fwd_mode=0", st->hit_ovf_host[2]);
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
         if (st->hit_ovf_host[0] == 0) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;

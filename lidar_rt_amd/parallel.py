@@ -88,13 +88,15 @@ class ShardedTracer:
         self.exchange = exchange
         self.sparse_max_fraction = 0.6
         self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | None
-        # build the LBVH for this rank's rays only (world >= 3).  Off by default: the kept count has to come back to the host
-        # (sort and tree sizes), and that read-back bubble costs more than the smaller build saves (S1M, N=8: 0.26 -> 0.36 ms)
-        self.cull_build = False
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # build the LBVH for this rank's rays only (lrt_build_for_rays; meaningful from 3 ranks on).  The library sizes the sort
+        # and the tree from the previous frame's kept count, so no read-back stalls the launch queue; on S1M the culled build
+        # beats the full one from ~1/8 of the frame per rank on (N=8: 0.25 -> 0.19-0.22 ms; N=4: 0.25 -> 0.27 ms), hence the
+        # default: on for 8 ranks and more
+        self.cull_build = self.world >= 8
 
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
         H, W = ray_o.shape[:2]
