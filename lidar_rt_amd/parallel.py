@@ -24,6 +24,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional, Tuple
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -97,6 +98,8 @@ class ShardedTracer:
         # beats the full one from ~1/8 of the frame per rank on (N=8: 0.25 -> 0.19-0.22 ms; N=4: 0.25 -> 0.27 ms), hence the
         # default: on for 8 ranks and more
         self.cull_build = self.world >= 8
+        if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
+            self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
 
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
         H, W = ray_o.shape[:2]
