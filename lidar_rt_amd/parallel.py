@@ -202,9 +202,7 @@ class ShardedTracer:
         dev = lay.flat.device
         idx = torch.nonzero(lay.views["accum"] > 0).squeeze(1)
         n = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
-        counts_t = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts_t, n, group=self.group)
-        counts = [int(c.item()) for c in counts_t]                    # the same list on every rank
+        counts = torch.cat(self._all_gather_rows(n)).tolist()         # the same list on every rank; ONE device->host copy
         nmax = max(counts)
         if self.exchange == "auto" and sum(counts) > self.sparse_max_fraction * P:
             return False
