@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
+    ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
+                    "configuration: the reference rebuilds its acceleration structure on every call, and so does the default step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,6 +144,7 @@ def main():
     for kv in args.opt:
         k_, v_ = kv.split("=")
         st.set_option(k_, int(v_))
+    st.refit_interval = max(args.refit_every, 0)
 
     def step():
         out, _ = tr.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg,
@@ -222,7 +225,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
-                       "step": ("LBVH rebuild + " if not args.no_build_in_step else "") + "forward + backward"
+                       "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
                                + (" + slab all_gather + gradient exchange (RCCL: all_gather of the touched Gaussians' rows, or one fused all_reduce)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange},

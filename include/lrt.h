@@ -68,6 +68,15 @@ int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* sc
                        const float* opacities, float scale_modifier, int n_rays, const float* ray_o, const float* ray_d,
                        void* stream);
 
+/* Refit: the LBVH of the last lrt_build (same P) keeps its primitive order and tree topology; records and boxes are
+ * recomputed from the given (moved) parameters.  About 0.4x the cost of lrt_build; results do not depend on the order
+ * (exhaustive traversal, hits sorted by (t, index)), only the traversal cost does as the primitives drift, so rebuild
+ * every few calls.  The reference builds its GAS with ALLOW_UPDATE (DLT/trace_surfels.cpp:63) but always rebuilds
+ * (:112-142); BASELINE configs[3] asks for the per-frame refit.  LRT_ERR_STATE if the last build was not an lrt_build
+ * of this P. */
+int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
+              const float* opacities, float scale_modifier, void* stream);
+
 /* Forward trace.  Requires a prior lrt_build with the same P.
  *   ray_o, ray_d (H,W,3); shs (P,M,3); sh_degree in 0..3, (sh_degree+1)^2 <= M;
  *   background: device pointer to 3 floats.

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
 
 EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_build_for_rays", "lrt_forward",
-           "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_grad_gather", "lrt_grad_scatter_add",
+           "lrt_refit", "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_grad_gather", "lrt_grad_scatter_add",
            # include/lrt_chamfer.h
            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
            "lrt_chamfer_set_option",
@@ -46,6 +46,8 @@ def load():
     lib.lrt_destroy.restype = None; lib.lrt_destroy.argtypes = [vp]
     lib.lrt_build.restype = ci
     lib.lrt_build.argtypes = [vp, ci, vp, vp, vp, vp, cf, vp]
+    lib.lrt_refit.restype = ci
+    lib.lrt_refit.argtypes = [vp, ci, vp, vp, vp, vp, cf, vp]
     lib.lrt_build_for_rays.restype = ci
     lib.lrt_build_for_rays.argtypes = [vp, ci, vp, vp, vp, vp, cf, ci, vp, vp, vp]
     lib.lrt_forward.restype = ci

@@ -67,6 +67,7 @@ struct lrt_state {
     float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
     int bounds_sel;
+    int order_P;        // vals_b holds the sorted order of an unculled build of this many primitives (lrt_refit), else -1
     unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
     // speculative sizing of the culled build: the sort and the tree are sized from the PREVIOUS culled build's kept count
     // (x1.25 + 4096), so that no read-back stalls the launch queue; cone_host = [kept, overflow] of the last build, valid after cone_ev
@@ -201,6 +202,17 @@ __global__ void k_bounds(int P, const float* __restrict__ means, const float* __
         const float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
         atomicMin(bounds + i, f2ord(l)); atomicMax(bounds + 3 + i, f2ord(h));
     }
+}
+
+// Refit: the parameters of one primitive into one 64-byte line (what k_morton does on the way in a full build).
+__global__ void k_pack(int P, const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ rots,
+                       const float* __restrict__ opac, float4* __restrict__ pack)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    pack[4 * (size_t)g] = make_float4(means[3 * g], means[3 * g + 1], means[3 * g + 2], opac[g]);
+    pack[4 * (size_t)g + 1] = make_float4(scales[2 * g], scales[2 * g + 1], rots[4 * g], rots[4 * g + 1]);
+    pack[4 * (size_t)g + 2] = make_float4(rots[4 * g + 2], rots[4 * g + 3], 0.f, 0.f);
 }
 
 // Morton keys of a ray-cone culled build: the kept primitives are compacted to the front of the key / index lists (their
@@ -1538,7 +1550,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_capacity(st, P, stream);
     if (rc) return rc;
-    st->P = -1; st->cone_flag_live = 0;
+    st->P = -1; st->cone_flag_live = 0; st->order_P = -1;
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     int Pk = P;                                                  // primitives that enter the LBVH
@@ -1615,6 +1627,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
     st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
+    st->order_P = (n_rays == 0 && P > 0) ? P : -1;
     return LRT_OK;
 }
 
@@ -1622,6 +1635,31 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
               const float* opac, float mod, void* stream_)
 {
     return build_impl("lrt_build", st, P, means, scales, rots, opac, mod, 0, nullptr, nullptr, stream_);
+}
+
+int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod,
+              void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_refit: null state");
+    if (P <= 0 || st->P != P || st->P_built != P || st->order_P != P)
+        LRT_FAIL(LRT_ERR_STATE, "lrt_refit: needs a preceding lrt_build of the same %d primitives (not a ray-culled one)", P);
+    if (!means || !scales || !rots || !opac) LRT_FAIL(LRT_ERR_ARG, "lrt_refit: null parameter pointer");
+    DeviceGuard dg(st->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    ScopedTimer tm(st, 0, stream);
+    const int TB = 256;
+    float4* pack = st->no_pack ? nullptr : st->pack;
+    if (pack) hipLaunchKernelGGL(k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack);
+    hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod,
+                       st->rec, st->aabb, (const float4*)pack, (const unsigned*)nullptr);
+    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
+    tree_layout(P, &nl, &L, cnt, off);
+    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
+    for (int l = 2; l <= L; l++)
+        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
+    HIPCHK(hipGetLastError());
+    st->mod = mod;
+    return LRT_OK;
 }
 
 int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac,

@@ -61,6 +61,9 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
     global tracer_2dgs
     if tracer_2dgs is None:
         tracer_2dgs = Tracer()
+    # opt.bvh_refit_interval = K > 0: K refits (lrt_refit: same order and topology, new records and boxes) between full LBVH
+    # builds while the number of Gaussians is unchanged; results do not depend on it.  0 = rebuild every call (the reference)
+    tracer_2dgs.optix_context.refit_interval = int(getattr(getattr(args, "opt", None), "bvh_refit_interval", 0) or 0)
     if decomp == "background":
         gaussian_assets = gaussian_assets[:1]
     elif decomp == "object":

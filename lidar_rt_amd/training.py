@@ -39,7 +39,8 @@ def default_options() -> SimpleNamespace:
         densify_from_iter=500, densify_until_iter=15_000, densification_interval=100, opacity_reset_interval=3000,
         densify_scale_threshold=0.0002, densify_grad_threshold=0.0002, densify_weight_threshold=0.0,
         prune_size_threshold=0.1, thresh_opa_prune=0.003, lambda_cd=0.01, lambda_depth_l1=0.1, lambda_intensity_l1=0.85,
-        lambda_intensity_l2=0.0, lambda_intensity_dssim=0.15, lambda_raydrop_bce=0.01, lambda_reg=0.01, use_rayhit=False)
+        lambda_intensity_l2=0.0, lambda_intensity_dssim=0.15, lambda_raydrop_bce=0.01, lambda_reg=0.01, use_rayhit=False,
+        bvh_refit_interval=0)   # not in the reference: K refits between full LBVH builds (renderer.raytracing), 0 = rebuild per call
 
 
 def expon_lr(step: int, lr_init: float, lr_final: float, delay_mult: float = 1.0, delay_steps: int = 0,

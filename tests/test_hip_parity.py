@@ -452,6 +452,39 @@ def test_ray_cone_culled_build_gives_the_same_results(n_slabs):
                 assert rel_l2(tt[k].grad.cpu().numpy().reshape(full["grads"][k].shape), full["grads"][k]) < 1e-5, (rep, k)
 
 
+def test_refit_keeps_the_order_and_gives_the_results_of_a_rebuild(s10k):
+    """lrt_refit after the Gaussians moved: same primitive order and tree topology, new records and boxes.  The traversal is
+    exhaustive and hits are ordered by (t, index), so image and gradients equal those of a full rebuild."""
+    from lidar_rt_amd.diff_lidar_tracer import _C
+    from tests.hip_util import settings, DEFAULT_OPTS
+    sc, o, d, dL = s10k
+    r = np.random.default_rng(5)
+    tr = Tracer()
+    for k, v in DEFAULT_OPTS.items():
+        tr.optix_context.set_option(k, v)
+    ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")
+    tr.optix_context.refit_interval = 3
+    try:
+        for it in range(6):                                                    # build, 3 refits, build, refit
+            moved = dict(sc)
+            moved["means"] = (sc["means"] + 0.02 * it * r.normal(size=sc["means"].shape)).astype(np.float32)
+            moved["scales"] = (sc["scales"] * np.exp(0.05 * it * r.normal(size=sc["scales"].shape))).astype(np.float32)
+            moved["opacities"] = np.clip(sc["opacities"] + 0.05 * it * r.normal(size=sc["opacities"].shape), 0.001, 0.99).astype(np.float32)
+            t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in moved.items()}
+            _C.build_from_gaussians(tr.optix_context, t["means"], t["scales"], t["rotations"], t["opacities"], 1.0)
+            out, acc = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"],
+                          scales=t["scales"], rotations=t["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+            out.backward(torch.as_tensor(dL, device="cuda:0"))
+            tr.optix_context.refit_interval = 0
+            ref = run_hip(moved, o, d, 3, scenes.BG_DEFAULT, dL)
+            tr.optix_context.refit_interval = 3
+            assert rel_l2(out.detach().cpu().numpy(), ref["out"]) < 1e-6, it
+            for k in GRADS:
+                assert rel_l2(t[k].grad.cpu().numpy(), ref["grads"][k]) < 1e-5, (it, k)
+    finally:
+        tr.optix_context.refit_interval = 0
+
+
 def test_speculative_culled_build_reports_lost_primitives():
     """The second culled build of a size is sized from the first one's kept count; if more primitives are kept than fit
     (forced here through the test hook), the forward built on it must not pass silently, and the build after it recovers."""
