@@ -19,6 +19,7 @@ def asset(noise):
     a.active_sh_degree = 3
     return a
 opt = training.default_options()
+opt.bvh_refit_interval = int(os.environ.get("REFIT", "0"))
 bg = torch.tensor([0.0, 0.0, 1.0], device=dev)
 frames = training.RangeFrames()
 args = types.SimpleNamespace(dynamic=False, opt=opt, pipe=types.SimpleNamespace())
