@@ -1778,7 +1778,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)
             // k_fwd_cr4: 8 waves per tile when every workgroup would get at most one tile anyway (few tiles: the launch lasts as
             // long as its heaviest tile), else 4
-            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 8 ? 8 : 4));
+            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 6 ? 8 : 4));
             const int per_cu = nw == 8 ? (st->wg4_per_cu + 1) / 2 : st->wg4_per_cu;
             if (wg4 && tp.c4_qlimit < 32u * (unsigned)nw + 8u) tp.c4_qlimit = 32u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
