@@ -105,284 +105,7 @@ __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ unsigned wave_sum_u(unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 
-// ---------------------------------------------------------------------------------------------------
-// Ray-cone culling for builds that serve only a subset of the frame's rays (one rank's azimuth slab): Gaussians whose
-// bounding sphere lies outside the cone around the rays cannot be hit and are left out of the LBVH.
-// cone words: [0..2] sum of unit directions (float), [3..5] / [6..8] min / max origin (ordered uint), [9] min cos(angle to the
-// axis) (ordered uint), [10] kept primitives (uint), [11] set when the kept primitives did not fit the speculative size.
-__global__ void k_cone_init(unsigned* cone)
-{
-    const int i = threadIdx.x;
-    if (i < 3) cone[i] = 0u; else if (i < 6) cone[i] = 0xffffffffu; else if (i < 9) cone[i] = 0u;
-    else if (i == 9) cone[i] = 0xffffffffu; else if (i == 10 || i == 11) cone[i] = 0u;
-}
-
-__global__ void __launch_bounds__(256) k_cone_axis(int n, const float* __restrict__ ro, const float* __restrict__ rd, unsigned* cone)
-{
-    float s[3] = {0.f, 0.f, 0.f}, lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const float dx = rd[3 * (size_t)r], dy = rd[3 * (size_t)r + 1], dz = rd[3 * (size_t)r + 2];
-        const float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f));
-        s[0] += dx * inv; s[1] += dy * inv; s[2] += dz * inv;
-        for (int i = 0; i < 3; i++) { const float o = ro[3 * (size_t)r + i]; lo[i] = fminf(lo[i], o); hi[i] = fmaxf(hi[i], o); }
-    }
-    for (int i = 0; i < 3; i++) {
-        for (int o = 32; o > 0; o >>= 1) s[i] += __shfl_xor(s[i], o);
-        lo[i] = wave_min(lo[i]); hi[i] = wave_max(hi[i]);
-    }
-    if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 3; i++) {
-            atomicAdd(reinterpret_cast<float*>(cone) + i, s[i]);
-            atomicMin(cone + 3 + i, f2ord(lo[i])); atomicMax(cone + 6 + i, f2ord(hi[i]));
-        }
-}
-
-__global__ void __launch_bounds__(256) k_cone_angle(int n, const float* __restrict__ rd, unsigned* cone)
-{
-    const float* sm = reinterpret_cast<const float*>(cone);
-    const float an = rsqrtf(fmaxf(sm[0] * sm[0] + sm[1] * sm[1] + sm[2] * sm[2], 1e-30f));
-    const float ax = sm[0] * an, ay = sm[1] * an, az = sm[2] * an;
-    float mc = 1.f;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const float dx = rd[3 * (size_t)r], dy = rd[3 * (size_t)r + 1], dz = rd[3 * (size_t)r + 2];
-        mc = fminf(mc, (dx * ax + dy * ay + dz * az) * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f)));
-    }
-    mc = wave_min(mc);
-    if ((threadIdx.x & 63) == 0) atomicMin(cone + 9, f2ord(mc));
-}
-
-// true = the Gaussian (centre, quad half-diagonal rho) cannot be hit by any ray of the cone (conservative).
-__device__ __forceinline__ bool cone_culls(const unsigned* __restrict__ cone, float x, float y, float z, float rho)
-{
-    const float* sm = reinterpret_cast<const float*>(cone);
-    const float s2 = sm[0] * sm[0] + sm[1] * sm[1] + sm[2] * sm[2];
-    const float mincos = ord2f(cone[9]);
-    if (!(s2 > 1e-12f) || !(mincos > 0.17f)) return false;             // no usable axis, or a cone wider than ~80 degrees: keep everything
-    const float an = rsqrtf(s2);
-    float o[3], ro2 = 0.f;
-    for (int i = 0; i < 3; i++) { const float l = ord2f(cone[3 + i]), h = ord2f(cone[6 + i]); o[i] = 0.5f * (l + h); ro2 += 0.25f * (h - l) * (h - l); }
-    const float vx = x - o[0], vy = y - o[1], vz = z - o[2];
-    const float L = sqrtf(vx * vx + vy * vy + vz * vz);
-    const float R = rho * 1.001f + sqrtf(ro2) + 1e-3f;                 // rays may start anywhere in the origins' bounding box
-    if (!(L > R)) return false;
-    const float ct = fminf(1.f, fmaxf(-1.f, (vx * sm[0] + vy * sm[1] + vz * sm[2]) * an / L));
-    const float half = acosf(fminf(1.f, mincos)) + 2e-3f;
-    return acosf(ct) > half + asinf(fminf(1.f, R / L)) + 1e-4f;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// LBVH build
-__device__ __forceinline__ float quad_half_diag(const float* __restrict__ scales, const float* __restrict__ opac, int g)
-{
-    const float f = lrt_cutoff(opac[g]), ex = scales[2 * (size_t)g] * f, ey = scales[2 * (size_t)g + 1] * f;
-    return sqrtf(ex * ex + ey * ey);
-}
-
-__global__ void k_bounds(int P, const float* __restrict__ means, const float* __restrict__ opac, unsigned* bounds,
-                         const float* __restrict__ scales, const unsigned* __restrict__ cone)
-{
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P; g += gridDim.x * blockDim.x) {
-        float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
-        bool ok = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
-        if (ok && cone) ok = !cone_culls(cone, x, y, z, quad_half_diag(scales, opac, g));
-        if (ok) {
-            lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
-            hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
-        }
-    }
-    for (int i = 0; i < 3; i++) { lo[i] = wave_min(lo[i]); hi[i] = wave_max(hi[i]); }
-    __shared__ float s_lo[4][3], s_hi[4][3];                     // 256-thread blocks: 4 waves -> one atomic set per block
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 3; i++) { s_lo[wv][i] = lo[i]; s_hi[wv][i] = hi[i]; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int i = threadIdx.x;
-        const float l = fminf(fminf(s_lo[0][i], s_lo[1][i]), fminf(s_lo[2][i], s_lo[3][i]));
-        const float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
-        atomicMin(bounds + i, f2ord(l)); atomicMax(bounds + 3 + i, f2ord(h));
-    }
-}
-
-// Refit: the parameters of one primitive into one 64-byte line (what k_morton does on the way in a full build).
-__global__ void k_pack(int P, const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ rots,
-                       const float* __restrict__ opac, float4* __restrict__ pack)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    pack[4 * (size_t)g] = make_float4(means[3 * g], means[3 * g + 1], means[3 * g + 2], opac[g]);
-    pack[4 * (size_t)g + 1] = make_float4(scales[2 * g], scales[2 * g + 1], rots[4 * g], rots[4 * g + 1]);
-    pack[4 * (size_t)g + 2] = make_float4(rots[4 * g + 2], rots[4 * g + 3], 0.f, 0.f);
-}
-
-// Morton keys of a ray-cone culled build: the kept primitives are compacted to the front of the key / index lists (their
-// order is fixed by the sort afterwards).  One workgroup takes 2048 consecutive primitives and ONE slot range from the global
-// counter (a returning atomic per wave on one address serialises in L2: 15.6 k of them cost ~0.25 ms at 1 M primitives).
-#define MC_ITEMS 8
-__global__ void __launch_bounds__(256) k_morton_cull(int P, const float* __restrict__ means, const float* __restrict__ opac,
-                                                     const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys,
-                                                     uint32_t* vals, const float* __restrict__ scales, unsigned* __restrict__ cone, unsigned keep_cap)
-{
-    __shared__ unsigned s_cnt[MC_ITEMS * 4], s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (blockIdx.x == 0 && tid < 6) bounds_next[tid] = tid < 3 ? 0xffffffffu : 0u;   // the other bounds set, for the next build
-    float lo[3], ext = 0.f;
-    for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
-    const float sc_ = ext > 0.f ? 2097151.0f / ext : 0.f;
-    uint64_t key[MC_ITEMS]; unsigned within[MC_ITEMS]; unsigned keepmask = 0u;
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; it++) {
-        const int g = (blockIdx.x * MC_ITEMS + it) * 256 + tid;
-        bool keep = false; key[it] = 0;
-        if (g < P) {
-            const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
-            keep = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f &&
-                   !cone_culls(cone, x, y, z, quad_half_diag(scales, opac, g));
-            if (keep) {
-                const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo[0]) * sc_, 0.f), 2097151.f);
-                const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo[1]) * sc_, 0.f), 2097151.f);
-                const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo[2]) * sc_, 0.f), 2097151.f);
-                key[it] = lrt_morton63(cx, cy, cz);
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        within[it] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_cnt[it * 4 + wv] = (unsigned)__popcll(m);
-        keepmask |= keep ? (1u << it) : 0u;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned tot = 0u;
-        for (int i = 0; i < MC_ITEMS * 4; i++) { const unsigned c = s_cnt[i]; s_cnt[i] = tot; tot += c; }   // exclusive prefix in place
-        s_base = tot ? atomicAdd(cone + 10, tot) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; it++) {
-        if (!((keepmask >> it) & 1u)) continue;
-        const unsigned slot = s_base + s_cnt[it * 4 + wv] + within[it];
-        if (slot >= keep_cap) { atomicOr(cone + 11, 1u); continue; }   // speculative size exceeded: reported by the next forward
-        keys[slot] = key[it]; vals[slot] = (uint32_t)((blockIdx.x * MC_ITEMS + it) * 256 + tid);
-    }
-}
-
-__global__ void k_morton(int P, const float* __restrict__ means, const float* __restrict__ opac,
-                         const unsigned* __restrict__ bounds, unsigned* __restrict__ bounds_next, uint64_t* keys, uint32_t* vals,
-                         const float* __restrict__ scales, const float* __restrict__ rots, float4* __restrict__ pack)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < 6) bounds_next[g] = g < 3 ? 0xffffffffu : 0u;        // the other bounds set, for the next build (no memset launches)
-    if (g >= P) return;
-    float lo[3], ext = 0.f;
-    for (int i = 0; i < 3; i++) { lo[i] = ord2f(bounds[i]); ext = fmaxf(ext, ord2f(bounds[3 + i]) - lo[i]); }
-    float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
-    bool ok = opac[g] > LRT_ALPHA_MIN && fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
-    uint64_t key = 0x7fffffffffffffffULL;                       // unhittable primitives sort to the end
-    if (ok) {
-        float s = ext > 0.f ? 2097151.0f / ext : 0.f;           // cubic cells: isotropic locality
-        uint32_t cx = (uint32_t)fminf(fmaxf((x - lo[0]) * s, 0.f), 2097151.f);
-        uint32_t cy = (uint32_t)fminf(fmaxf((y - lo[1]) * s, 0.f), 2097151.f);
-        uint32_t cz = (uint32_t)fminf(fmaxf((z - lo[2]) * s, 0.f), 2097151.f);
-        key = lrt_morton63(cx, cy, cz);
-    }
-    keys[g] = key; vals[g] = (uint32_t)g;
-    if (pack) {   // the parameters of one primitive in one 64-byte line: k_make_records gathers them by sorted index, and a
-                  // gather from four separate arrays (12/8/16/4 bytes each) costs four sectors per primitive
-        pack[4 * (size_t)g] = make_float4(x, y, z, opac[g]);
-        pack[4 * (size_t)g + 1] = make_float4(scales[2 * g], scales[2 * g + 1], rots[4 * g], rots[4 * g + 1]);
-        pack[4 * (size_t)g + 2] = make_float4(rots[4 * g + 2], rots[4 * g + 3], 0.f, 0.f);
-    }
-}
-
-// One thread per sorted slot: quad record + AABB from the raw Gaussian (fused build2DRectangle).
-__global__ void k_make_records(int P, const uint32_t* __restrict__ order, const float* __restrict__ means,
-                               const float* __restrict__ scales, const float* __restrict__ rots,
-                               const float* __restrict__ opac, float mod, float* __restrict__ rec,
-                               float* __restrict__ aabb, const float4* __restrict__ pack, const unsigned* __restrict__ kept_ptr)
-{
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int Ppad = (P + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
-    if (k >= Ppad) return;
-    const int kept = kept_ptr ? min((int)*kept_ptr, P) : P;      // speculatively sized culled build: slots [kept, P) hold sentinel keys
-    if (k >= kept) {                                // padding so that every leaf holds LRT_LEAF records
-        if (k < P) { float* a = aabb + (size_t)k * 6; a[0] = a[1] = a[2] = 1e30f; a[3] = a[4] = a[5] = -1e30f; }
-        float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
-        dst[0] = make_float4(0.f, 0.f, 1.f, -1.f); dst[1] = make_float4(0.f, 0.f, 0.f, -1.f);
-        dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    int g = (int)order[k];
-    float mu[3], sc[2], q[4], op;
-    if (pack) {
-        const float4 a = pack[4 * (size_t)g], b = pack[4 * (size_t)g + 1], c = pack[4 * (size_t)g + 2];
-        mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; op = a.w; sc[0] = b.x; sc[1] = b.y; q[0] = b.z; q[1] = b.w; q[2] = c.x; q[3] = c.y;
-    } else {
-        mu[0] = means[3 * g]; mu[1] = means[3 * g + 1]; mu[2] = means[3 * g + 2]; op = opac[g];
-        sc[0] = scales[2 * g]; sc[1] = scales[2 * g + 1];
-        q[0] = rots[4 * g]; q[1] = rots[4 * g + 1]; q[2] = rots[4 * g + 2]; q[3] = rots[4 * g + 3];
-    }
-    float r[LRT_REC_FLOATS]; LrtSplatAux aux;
-    lrt_make_splat(mu, sc, q, op, mod, g, r, &aux);
-    float4* dst = reinterpret_cast<float4*>(rec + (size_t)k * LRT_REC_FLOATS);
-    dst[0] = make_float4(r[0], r[1], r[2], r[3]);   dst[1] = make_float4(r[4], r[5], r[6], r[7]);
-    dst[2] = make_float4(r[8], r[9], r[10], r[11]); dst[3] = make_float4(r[12], r[13], r[14], r[15]);
-    float* a = aabb + (size_t)k * 6;
-    a[0] = aux.lo[0]; a[1] = aux.lo[1]; a[2] = aux.lo[2]; a[3] = aux.hi[0]; a[4] = aux.hi[1]; a[5] = aux.hi[2];
-}
-
-// Level-1 nodes: child c of node j is leaf 8j+c = sorted primitives [LEAF*(8j+c), +LEAF).
-__global__ void k_level1(int P, int n_nodes_l1, int node_off, const float* __restrict__ aabb, float* __restrict__ nodes,
-                         float* __restrict__ nodes_aos)
-{
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = tid >> 3, c = tid & 7;
-    if (j >= n_nodes_l1) return;
-    int leaf = j * 8 + c;
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    for (int k = leaf * LRT_LEAF; k < leaf * LRT_LEAF + LRT_LEAF && k < P; k++) {
-        const float* a = aabb + (size_t)k * 6;
-        for (int i = 0; i < 3; i++) { lo[i] = fminf(lo[i], a[i]); hi[i] = fmaxf(hi[i], a[3 + i]); }
-    }
-    float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
-    const bool empty = lo[0] > hi[0];
-    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
-    if (c == 0) { nd[48] = __int_as_float(j * 8); nd[49] = __int_as_float(1); }   // children = leaves, base leaf 8j
-    float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
-    // AoS child = (lo.x hi.x lo.y hi.y | lo.z hi.z ptr flags): each axis' two planes are one operand pair of v_pk_fma_f32
-    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], hi[0], lo[1], hi[1]);
-    na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
-                  : make_float4(lo[2], hi[2], __int_as_float(leaf), __int_as_float(1));       // flags: 1 = leaf, 2 = empty
-}
-
-// Level-l nodes (l >= 2): child c of node j is node 8j+c of level l-1.
-__device__ __forceinline__ void upper_child(int tid, int n_nodes, int node_off, int n_child, int child_off, float* nodes, float* nodes_aos)
-{
-    int j = tid >> 3, c = tid & 7;
-    if (j >= n_nodes) return;
-    int ch = j * 8 + c;
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    if (ch < n_child) {
-        const float* cn = nodes + (size_t)(child_off + ch) * LRT_NODE_FLOATS;
-        for (int e = 0; e < 8; e++) {
-            if (cn[e] >= LRT_EMPTY) continue;                   // empty grandchild
-            for (int i = 0; i < 3; i++) { lo[i] = fminf(lo[i], cn[i * 8 + e]); hi[i] = fmaxf(hi[i], cn[24 + i * 8 + e]); }
-        }
-    }
-    float* nd = nodes + (size_t)(node_off + j) * LRT_NODE_FLOATS;
-    const bool empty = lo[0] > hi[0];
-    for (int i = 0; i < 3; i++) { nd[i * 8 + c] = empty ? LRT_EMPTY : lo[i]; nd[24 + i * 8 + c] = empty ? LRT_EMPTY : hi[i]; }
-    if (c == 0) { nd[48] = __int_as_float(child_off + j * 8); nd[49] = __int_as_float(0); }
-    float4* na = reinterpret_cast<float4*>(nodes_aos + (size_t)(node_off + j) * LRT_NODE_FLOATS + c * 8);
-    na[0] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, LRT_EMPTY, LRT_EMPTY) : make_float4(lo[0], hi[0], lo[1], hi[1]);
-    na[1] = empty ? make_float4(LRT_EMPTY, LRT_EMPTY, __int_as_float(0), __int_as_float(2))
-                  : make_float4(lo[2], hi[2], __int_as_float(child_off + ch), __int_as_float(0));
-}
-
-__global__ void k_upper(int n_nodes, int node_off, int n_child, int child_off, float* nodes, float* nodes_aos)
-{
-    upper_child(blockIdx.x * blockDim.x + threadIdx.x, n_nodes, node_off, n_child, child_off, nodes, nodes_aos);
-}
-
+#include "lrt_build.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Trace
@@ -551,402 +274,7 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
     return alpha;
 }
 
-// Backward by REPLAY of the hit record the forward wrote (no traversal; the reference re-traces, backward.cu:513).
-// One lane per ray, same 64-ray tiles as the forward so that neighbouring lanes scatter into neighbouring Gaussians.
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_bwd_replay(const TraceParams p)
-{
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= p.n_tiles) return;
-    const int TWm = (1 << p.tw_log2) - 1, TH = 64 >> p.tw_log2;
-    const int ty = tile % p.tiles_y, tx = tile / p.tiles_y;
-    const int h = ty * TH + (lane >> p.tw_log2), w = (tx << p.tw_log2) + (lane & TWm);
-    const bool valid = (h < p.H) && (w < p.W);
-    const size_t r = valid ? ((size_t)h * p.W + w) : 0;
-    float o[3], d[3];
-    for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * r + i]; d[i] = p.ray_d[3 * r + i]; }
-    float b[16];
-    lrt_sh_basis(p.deg, d, b);
-    float dL[LRT_NCH], fin[LRT_NCH];
-    for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * r + i]; fin[i] = p.out9_in[LRT_NCH * r + i]; }
-    const float dL_dbg = dL[0] * p.bg[0] + dL[1] * p.bg[1] + dL[2] * p.bg[2];
-    RayAcc a = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!SCATTER && valid) {
-        float4* rp = p.ray_pk + 4 * r;
-        rp[0] = make_float4(o[0], o[1], o[2], dL[3]); rp[1] = make_float4(d[0], d[1], d[2], 0.f);
-        rp[2] = make_float4(dL[0], dL[1], dL[2], 0.f); rp[3] = make_float4(dL[5], dL[6], dL[7], 0.f);
-    }
-    const int n = valid ? min(p.hit_n[r], p.hit_cap) : 0;
-    for (int j = 0; __any(j < n); ++j) {
-        if (j < n) {
-            const size_t id = r * (size_t)p.hit_cap + j;
-            const float t = p.hit_t[id];
-            const int g = p.hit_g[id];
-            bwd_hit<false, SCATTER>(p, o, d, b, p.nsh, dL, fin, dL_dbg, t, g, 0.f, a, id);
-            if (!SCATTER) {                          // dense (gidx, id) key list for the sort: slot = exclusive_scan(hit_n)[r] + j
-                const unsigned slot = p.hit_off[r] + (unsigned)j;
-                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << p.id_bits) | (unsigned long long)id;
-            }
-        }
-    }
-}
-
-// Replay for the sorted-reduction backward, ONE RAY PER WAVE: lane j takes the j-th composited hit of the ray (the
-// record is ray-major, so the loads are coalesced), the transmittance is a wave prefix product and the running sums
-// of the reference's sequential loop (C, D, N "so far", backward.cu:576-604) are wave prefix sums.  131k independent
-// ray tasks instead of 2k waves each walking 64 rays hit by hit.  Writes (t, dL/dalpha, +-w) per hit, the dense
-// (gidx, id) key list and the per-ray pack.
-// FAST: the deferred-colour forward left (weight, op*G) in hit_wa and k_fwd_colour left the hit's colour in hit_pk, so the
-// per-hit gathers of the Gaussian (40 B) and of its SH table (192 B) are not repeated here.
-template <bool FAST>
-__global__ void __launch_bounds__(64) k_bwd_prep(const TraceParams p)
-{
-    const int lane = threadIdx.x;
-    const int nsh = p.nsh;
-    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
-    for (unsigned r = blockIdx.x; r < (unsigned)p.hw; r += gridDim.x) {
-        const int n = min(p.hit_n[r], p.hit_cap);
-        if (n == 0) continue;
-        float o[3], d[3], dL[LRT_NCH], fin[LRT_NCH];
-        for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * (size_t)r + i]; d[i] = p.ray_d[3 * (size_t)r + i]; }
-        for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * (size_t)r + i]; fin[i] = p.out9_in[LRT_NCH * (size_t)r + i]; }
-        if (lane < 4) {
-            const float4 v = lane == 0 ? make_float4(o[0], o[1], o[2], dL[3]) : (lane == 1 ? make_float4(d[0], d[1], d[2], 0.f) :
-                             (lane == 2 ? make_float4(dL[0], dL[1], dL[2], 0.f) : make_float4(dL[5], dL[6], dL[7], 0.f)));
-            p.ray_pk[4 * (size_t)r + lane] = v;
-        }
-        const float dL_dbg = dL[0] * bg0 + dL[1] * bg1 + dL[2] * bg2;
-        const bool need_n = (dL[5] != 0.f) || (dL[6] != 0.f) || (dL[7] != 0.f);
-        float b[16];
-        lrt_sh_basis(p.deg, d, b);
-        const unsigned off = p.hit_off[r];
-        float T_run = 1.f, rC0 = 0.f, rC1 = 0.f, rC2 = 0.f, rD = 0.f, rN0 = 0.f, rN1 = 0.f, rN2 = 0.f;
-        for (int cb = 0; cb < n; cb += 64) {
-            const int j = cb + lane;
-            const bool live = j < n;
-            const size_t id = (size_t)r * p.hit_cap + (live ? j : cb);
-            const float t = p.hit_t[id];
-            const int g = p.hit_g[id];
-            float c0, c1, c2, ao, n0 = 0.f, n1 = 0.f, n2 = 0.f; bool cl0;
-            if (FAST) {
-                const float4 cc = p.hit_pk[id];                      // written by k_fwd_colour, overwritten below by the same lane
-                c0 = cc.x; c1 = cc.y; c2 = cc.z; cl0 = cc.w != 0.f;
-                ao = p.hit_wa[id].y;
-                if (need_n) {                                        // normals only matter for upstream gradients on channels 5..7 (D3)
-                    const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
-                    float R[9];
-                    lrt_quat_to_R(q, R);
-                    n0 = R[2]; n1 = R[5]; n2 = R[8];
-                }
-            } else {
-                const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
-                const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
-                const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
-                sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
-                LrtHitGeom hg;
-                lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-                ao = p.opac[g] * hg.G;
-                n0 = hg.R[2]; n1 = hg.R[5]; n2 = hg.R[8];
-            }
-            const float alpha = fminf(LRT_ALPHA_MAX, ao);
-            const float incl = wave_incl_prod(live ? (1.f - alpha) : 1.f);
-            float excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = 1.f;
-            const float Tk = T_run * excl;
-            const float wgt = live ? alpha * Tk : 0.f;
-            const float sC0 = rC0 + wave_incl_sum(wgt * c0), sC1 = rC1 + wave_incl_sum(wgt * c1), sC2 = rC2 + wave_incl_sum(wgt * c2);
-            const float sD = rD + wave_incl_sum(wgt * t);
-            const float sN0 = rN0 + wave_incl_sum(wgt * n0), sN1 = rN1 + wave_incl_sum(wgt * n1), sN2 = rN2 + wave_incl_sum(wgt * n2);
-            const float i1a = 1.0f / (1.0f - alpha);
-            float dLa = dL[0] * (Tk * c0 - (fin[0] - sC0) * i1a) + dL[1] * (Tk * c1 - (fin[1] - sC1) * i1a) +
-                        dL[2] * (Tk * c2 - (fin[2] - sC2) * i1a);
-            dLa += dL_dbg * (-fin[8] * i1a);                        // D1 (backward.cu:595-598)
-            dLa += dL[3] * (Tk * t - (fin[3] - sD) * i1a);
-            dLa += dL[5] * (Tk * n0 - (fin[5] - sN0) * i1a) + dL[6] * (Tk * n1 - (fin[6] - sN1) * i1a) +
-                   dL[7] * (Tk * n2 - (fin[7] - sN2) * i1a);        // D3
-            dLa *= (ao > LRT_ALPHA_MAX) ? 0.f : 1.f;                // backward.cu:607-608
-            if (live) {
-                p.hit_pk[id] = make_float4(t, dLa, cl0 ? -wgt : wgt, 0.f);
-                const unsigned slot = off + (unsigned)j;
-                if (slot < p.key_cap) p.hit_keys[slot] = ((unsigned long long)(unsigned)g << p.id_bits) | (unsigned long long)id;
-            }
-            // carries for rays with more than 64 composited hits
-            T_run *= rdl(incl, 63);
-            rC0 = rdl(sC0, 63); rC1 = rdl(sC1, 63); rC2 = rdl(sC2, 63); rD = rdl(sD, 63);
-            rN0 = rdl(sN0, 63); rN1 = rdl(sN1, 63); rN2 = rdl(sN2, 63);
-        }
-    }
-}
-
-// Sorted segmented reduction of the per-hit gradients (deterministic, almost atomic-free): thread c owns CH consecutive
-// entries of the (g, id)-sorted hit list, accumulates each run of equal g in registers and writes it once; only runs
-// that continue across a chunk boundary use atomics.
-#define LRT_RED_CH 16
-__global__ void __launch_bounds__(256) k_bwd_reduce(const TraceParams p)
-{
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long i0 = (unsigned long long)c * LRT_RED_CH;
-    if (i0 >= p.n_hits) return;
-    const unsigned long long i1 = (i0 + LRT_RED_CH < p.n_hits) ? i0 + LRT_RED_CH : p.n_hits;
-    const int nsh = p.nsh;
-    float am[3], as[2], ar[4], aop, ash[48];
-    float mu[3], sc[2], q[4], op = 0.f;
-    int cur = -1; bool shared = false;
-    auto flush = [&](int g, bool sh_) {
-        float* dm = p.d_means + 3 * (size_t)g; float* ds = p.d_scales + 2 * (size_t)g; float* dr = p.d_rots + 4 * (size_t)g;
-        float* dsh = p.d_shs + (size_t)g * p.M * 3;
-        if (sh_) {
-            for (int k = 0; k < 3; k++) unsafeAtomicAdd(dm + k, am[k]);
-            for (int k = 0; k < 2; k++) unsafeAtomicAdd(ds + k, as[k]);
-            for (int k = 0; k < 4; k++) unsafeAtomicAdd(dr + k, ar[k]);
-            unsafeAtomicAdd(p.d_opac + g, aop);
-#pragma unroll
-            for (int k = 0; k < 48; k++) if (k < 3 * nsh) unsafeAtomicAdd(dsh + k, ash[k]);
-        } else {
-            for (int k = 0; k < 3; k++) dm[k] = am[k];
-            for (int k = 0; k < 2; k++) ds[k] = as[k];
-            for (int k = 0; k < 4; k++) dr[k] = ar[k];
-            p.d_opac[g] = aop;
-#pragma unroll
-            for (int k = 0; k < 48; k++) if (k < 3 * nsh) dsh[k] = ash[k];
-        }
-    };
-    for (unsigned long long i = i0; i < i1; ++i) {
-        const unsigned long long key = p.sorted_keys[i];
-        const int g = (int)(key >> p.id_bits);
-        const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
-        if (g != cur) {
-            if (cur >= 0) flush(cur, shared);
-            cur = g;
-            shared = (i == i0) && (i0 > 0) && ((int)(p.sorted_keys[i0 - 1] >> p.id_bits) == g);
-            for (int k = 0; k < 3; k++) { mu[k] = p.means[3 * (size_t)g + k]; am[k] = 0.f; }
-            for (int k = 0; k < 2; k++) { sc[k] = p.scales[2 * (size_t)g + k]; as[k] = 0.f; }
-            for (int k = 0; k < 4; k++) { q[k] = p.rots[4 * (size_t)g + k]; ar[k] = 0.f; }
-            op = p.opac[g]; aop = 0.f;
-#pragma unroll
-            for (int k = 0; k < 48; k++) ash[k] = 0.f;
-        }
-        const unsigned r = id / (unsigned)p.hit_cap;
-        const float4 hp = p.hit_pk[id];
-        const float t = hp.x, da = hp.y, ws = hp.z;
-        const float w = fabsf(ws);
-        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
-        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
-        const float dL[LRT_NCH] = {r2_.x, r2_.y, r2_.z, r0_.w, 0.f, r3_.x, r3_.y, r3_.z, 0.f};
-        LrtHitGeom hg;
-        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-        aop += hg.G * da;
-        const float dNgs[3] = {dL[5] * w, dL[6] * w, dL[7] * w};
-        LrtHitGrad gr;
-        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, dL[3] * w, dNgs, &gr);
-        for (int k = 0; k < 3; k++) am[k] += gr.d_mean[k];
-        for (int k = 0; k < 2; k++) as[k] += gr.d_scale[k];
-        for (int k = 0; k < 4; k++) ar[k] += gr.d_rot[k];
-        float b[16];
-        lrt_sh_basis(p.deg, d, b);
-        const float r0 = (ws < 0.f) ? 0.f : dL[0] * w, r1 = dL[1] * w, r2 = dL[2] * w;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < nsh) { ash[3 * k] += b[k] * r0; ash[3 * k + 1] += b[k] * r1; ash[3 * k + 2] += b[k] * r2; }
-    }
-    if (cur >= 0) {
-        const bool cont = (i1 < p.n_hits) && ((int)(p.sorted_keys[i1] >> p.id_bits) == cur);
-        flush(cur, shared || cont);
-    }
-}
-
-// Lane-per-hit variant of the segmented reduction: every lane of a wave takes ONE entry of the (g, id)-sorted hit
-// list, so the 64 gathers of a wave are independent and in flight together; the per-hit gradients are then combined
-// with a segmented inclusive scan over the wave (segments = runs of equal gidx, contiguous because sorted) and the
-// last lane of each run writes the total -- plainly if the run lies inside the wave, with atomics if it continues
-// in a neighbouring wave.
-__device__ __forceinline__ float seg_step(float v, int off, bool same, int lane)
-{
-    const float y = __shfl_up(v, off);
-    return (same && lane >= off) ? v + y : v;
-}
-
-// Variant of the reduction ("transposed"): the 58 per-hit components go through LDS as a [hit][component] matrix, lane c then
-// walks its column hit by hit and adds; at the end of a run of equal gidx the 58 lanes store the Gaussian's gradient row with ONE
-// store instruction (lane c -> component c).  No 58 x 6 dependent DPP steps and no 58 single-lane stores per run.
-#define R3_STRIDE 59                       // odd row stride: conflict-free when lane = hit writes and when lane = component reads
-__global__ void __launch_bounds__(256) k_bwd_reduce3(const TraceParams p)
-{
-    __shared__ float s_m[4][32 * R3_STRIDE];
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool live = i < p.n_hits;
-    const unsigned long long wave0 = i - (unsigned long long)lane;
-    const unsigned long long key = live ? p.sorted_keys[i] : ~0ull;
-    const int g = live ? (int)(key >> p.id_bits) : -1;
-    const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
-    const int nsh = p.nsh;
-    float acc[10], ash[48];
-#pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 48; k++) ash[k] = 0.f;
-    if (live) {
-        const unsigned r = id / (unsigned)p.hit_cap;
-        const float4 hp = p.hit_pk[id];
-        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
-        const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
-        const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
-        const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
-        const float op = p.opac[g];
-        const float t = hp.x, da = hp.y, ws = hp.z, w = fabsf(ws);
-        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
-        LrtHitGeom hg;
-        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-        const float dNgs[3] = {r3_.x * w, r3_.y * w, r3_.z * w};
-        LrtHitGrad gr;
-        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, r0_.w * w, dNgs, &gr);
-        acc[0] = gr.d_mean[0]; acc[1] = gr.d_mean[1]; acc[2] = gr.d_mean[2];
-        acc[3] = gr.d_scale[0]; acc[4] = gr.d_scale[1];
-        acc[5] = gr.d_rot[0]; acc[6] = gr.d_rot[1]; acc[7] = gr.d_rot[2]; acc[8] = gr.d_rot[3];
-        acc[9] = hg.G * da;
-        float b[16];
-        lrt_sh_basis(p.deg, d, b);
-        const float c0 = (ws < 0.f) ? 0.f : r2_.x * w, c1 = r2_.y * w, c2 = r2_.z * w;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < nsh) { ash[3 * k] = b[k] * c0; ash[3 * k + 1] = b[k] * c1; ash[3 * k + 2] = b[k] * c2; }
-    }
-    const int wv = threadIdx.x >> 6;
-    float* m = s_m[wv];
-    const int gn = __shfl_down(g, 1);
-    const bool tail = live && (lane == 63 || gn != g);
-    const unsigned long long tails = __ballot(tail);
-    if (!tails) return;
-    // does the first / last run of this wave continue in a neighbouring wave?  (then its total is added atomically)
-    const int g_first = __builtin_amdgcn_readlane(g, 0), g_last = __builtin_amdgcn_readlane(g, 63);
-    bool sh_first = false, sh_last = false;
-    if (wave0 > 0) sh_first = ((int)(p.sorted_keys[wave0 - 1] >> p.id_bits) == g_first);
-    if (wave0 + 64 < p.n_hits) sh_last = ((int)(p.sorted_keys[wave0 + 64] >> p.id_bits) == g_last);
-    const int nc = 10 + 3 * nsh;                               // live components
-    const int M3 = p.M * 3;
-    float run = 0.f;
-    for (int half = 0; half < 2; half++) {
-        if ((lane >> 5) == half) {                               // lanes of this half publish their hit's components
-            float* row = m + (lane & 31) * R3_STRIDE;
-#pragma unroll
-            for (int k = 0; k < 10; k++) row[k] = acc[k];
-#pragma unroll
-            for (int k = 0; k < 48; k++) if (k < 3 * nsh) row[10 + k] = ash[k];
-        }
-        // wave-local LDS: in-order, no barrier needed inside a wave
-        for (int j = 0; j < 32; j++) {
-            const int hj = 32 * half + j;
-            if (lane < nc) run += m[j * R3_STRIDE + lane];
-            if ((tails >> hj) & 1ull) {
-                const int gj = __builtin_amdgcn_readlane(g, hj);
-                const bool shared = ((gj == g_first) && sh_first) || (hj == 63 && sh_last);
-                if (lane < nc) {
-                    float* dst = lane < 3 ? p.d_means + 3 * (size_t)gj + lane
-                               : lane < 5 ? p.d_scales + 2 * (size_t)gj + (lane - 3)
-                               : lane < 9 ? p.d_rots + 4 * (size_t)gj + (lane - 5)
-                               : lane == 9 ? p.d_opac + gj
-                               : p.d_shs + (size_t)gj * M3 + (lane - 10);
-                    if (shared) unsafeAtomicAdd(dst, run); else *dst = run;
-                }
-                run = 0.f;
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) k_bwd_reduce2(const TraceParams p)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool live = i < p.n_hits;
-    const unsigned long long wave0 = i - (unsigned long long)lane;
-    const unsigned long long key = live ? p.sorted_keys[i] : ~0ull;
-    const int g = live ? (int)(key >> p.id_bits) : -1;
-    const unsigned id = (unsigned)(key & ((1ull << p.id_bits) - 1ull));
-    const int nsh = p.nsh;
-    float acc[10], ash[48];
-#pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 48; k++) ash[k] = 0.f;
-    if (live) {
-        const unsigned r = id / (unsigned)p.hit_cap;
-        const float4 hp = p.hit_pk[id];
-        const float4 r0_ = p.ray_pk[4 * (size_t)r], r1_ = p.ray_pk[4 * (size_t)r + 1], r2_ = p.ray_pk[4 * (size_t)r + 2], r3_ = p.ray_pk[4 * (size_t)r + 3];
-        const float mu[3] = {p.means[3 * (size_t)g], p.means[3 * (size_t)g + 1], p.means[3 * (size_t)g + 2]};
-        const float sc[2] = {p.scales[2 * (size_t)g], p.scales[2 * (size_t)g + 1]};
-        const float q[4] = {p.rots[4 * (size_t)g], p.rots[4 * (size_t)g + 1], p.rots[4 * (size_t)g + 2], p.rots[4 * (size_t)g + 3]};
-        const float op = p.opac[g];
-        const float t = hp.x, da = hp.y, ws = hp.z, w = fabsf(ws);
-        const float o[3] = {r0_.x, r0_.y, r0_.z}, d[3] = {r1_.x, r1_.y, r1_.z};
-        LrtHitGeom hg;
-        lrt_hit_geom(o, d, t, mu, sc, q, p.mod, &hg);
-        const float dNgs[3] = {r3_.x * w, r3_.y * w, r3_.z * w};
-        LrtHitGrad gr;
-        lrt_hit_backward(&hg, o, d, mu, sc, q, op, op * da, r0_.w * w, dNgs, &gr);
-        acc[0] = gr.d_mean[0]; acc[1] = gr.d_mean[1]; acc[2] = gr.d_mean[2];
-        acc[3] = gr.d_scale[0]; acc[4] = gr.d_scale[1];
-        acc[5] = gr.d_rot[0]; acc[6] = gr.d_rot[1]; acc[7] = gr.d_rot[2]; acc[8] = gr.d_rot[3];
-        acc[9] = hg.G * da;
-        float b[16];
-        lrt_sh_basis(p.deg, d, b);
-        const float c0 = (ws < 0.f) ? 0.f : r2_.x * w, c1 = r2_.y * w, c2 = r2_.z * w;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < nsh) { ash[3 * k] = b[k] * c0; ash[3 * k + 1] = b[k] * c1; ash[3 * k + 2] = b[k] * c2; }
-    }
-    // Segmented inclusive scan over the runs of equal g, on the DPP network (no LDS crossbar traffic): four row_shr steps
-    // inside the 16-lane rows, then the previous row's last lane (row_bcast:15, rows 1 and 3) and lane 31 (row_bcast:31,
-    // rows 2 and 3) as carries.  The keys are sorted, so "same run" = equal g at both ends; lanes without a source read -2.
-    float mk[6];
-    {
-        const int g1 = __builtin_amdgcn_update_dpp(-2, g, 0x111, 0xf, 0xf, false), g2 = __builtin_amdgcn_update_dpp(-2, g, 0x112, 0xf, 0xf, false);
-        const int g4 = __builtin_amdgcn_update_dpp(-2, g, 0x114, 0xf, 0xf, false), g8 = __builtin_amdgcn_update_dpp(-2, g, 0x118, 0xf, 0xf, false);
-        const int gA = __builtin_amdgcn_update_dpp(-2, g, 0x142, 0xa, 0xf, false), gB = __builtin_amdgcn_update_dpp(-2, g, 0x143, 0xc, 0xf, false);
-        mk[0] = g1 == g ? 1.f : 0.f; mk[1] = g2 == g ? 1.f : 0.f; mk[2] = g4 == g ? 1.f : 0.f; mk[3] = g8 == g ? 1.f : 0.f;
-        mk[4] = gA == g ? 1.f : 0.f; mk[5] = gB == g ? 1.f : 0.f;
-    }
-#define SEG_SCAN(x) do { \
-        x = fmaf(dpp_z<0x111>(x), mk[0], x); x = fmaf(dpp_z<0x112>(x), mk[1], x); \
-        x = fmaf(dpp_z<0x114>(x), mk[2], x); x = fmaf(dpp_z<0x118>(x), mk[3], x); \
-        x = fmaf(dpp_f<0x142, 0xa>(0.f, x), mk[4], x); x = fmaf(dpp_f<0x143, 0xc>(0.f, x), mk[5], x); } while (0)
-#pragma unroll
-    for (int k = 0; k < 10; k++) SEG_SCAN(acc[k]);
-#pragma unroll
-    for (int k = 0; k < 48; k++) if (k < 3 * nsh) SEG_SCAN(ash[k]);
-#undef SEG_SCAN
-    bool same[1];
-    { const int gp = __shfl_up(g, 1); same[0] = (lane >= 1) && (gp == g); }
-    const int gn = __shfl_down(g, 1);
-    const bool tail = live && (lane == 63 || gn != g);
-    // run head of this lane's run (all lanes take part in the ballot, so it precedes the early return)
-    const unsigned long long heads = __ballot(!same[0]);                 // lanes whose lower neighbour differs, and lane 0
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    const bool starts_at0 = (63 - __clzll((long long)below)) == 0;
-    if (!tail) return;
-    bool shared = false;
-    if (starts_at0 && wave0 > 0) shared = ((int)(p.sorted_keys[wave0 - 1] >> p.id_bits) == g);
-    if (lane == 63 && i + 1 < p.n_hits) shared = shared || ((int)(p.sorted_keys[i + 1] >> p.id_bits) == g);
-    float* dm = p.d_means + 3 * (size_t)g; float* ds = p.d_scales + 2 * (size_t)g; float* dr = p.d_rots + 4 * (size_t)g;
-    float* dsh = p.d_shs + (size_t)g * p.M * 3;
-    if (shared) {
-        for (int k = 0; k < 3; k++) unsafeAtomicAdd(dm + k, acc[k]);
-        for (int k = 0; k < 2; k++) unsafeAtomicAdd(ds + k, acc[3 + k]);
-        for (int k = 0; k < 4; k++) unsafeAtomicAdd(dr + k, acc[5 + k]);
-        unsafeAtomicAdd(p.d_opac + g, acc[9]);
-#pragma unroll
-        for (int k = 0; k < 48; k++) if (k < 3 * nsh) unsafeAtomicAdd(dsh + k, ash[k]);
-    } else {
-        for (int k = 0; k < 3; k++) dm[k] = acc[k];
-        for (int k = 0; k < 2; k++) ds[k] = acc[3 + k];
-        for (int k = 0; k < 4; k++) dr[k] = acc[5 + k];
-        p.d_opac[g] = acc[9];
-#pragma unroll
-        for (int k = 0; k < 48; k++) if (k < 3 * nsh) dsh[k] = ash[k];
-    }
-}
+#include "lrt_backward.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Sparse gradient exchange helpers (azimuth-sharded backward): row r <-> Gaussian idx[r], see include/lrt.h.
@@ -965,237 +293,7 @@ __global__ void __launch_bounds__(256) k_grad_rows(int n, int width, const int32
     if (GATHER) rows[t] = *p; else *p += rows[t];
 }
 
-#define CSWAP(a, b) do { unsigned lo_ = (a) < (b) ? (a) : (b); unsigned hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
-
-template <bool BWD>
-__global__ void __launch_bounds__(256, 2) k_trace(const TraceParams p, const float* __restrict__ g_rec,
-                                                const float* __restrict__ g_nodes)
-{
-    __shared__ float s_t[4][LRT_CHUNK][64];
-    __shared__ int   s_g[4][LRT_CHUNK][64];
-    __shared__ float s_a[4][LRT_CHUNK][64];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int TWm = (1 << p.tw_log2) - 1;
-    const int TH = 64 >> p.tw_log2;
-    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
-    const int nsh = p.nsh;
-    unsigned st_cand = 0, st_comp = 0, st_pass = 0, st_nodes = 0, st_prims = 0, st_ins = 0;
-    unsigned long long st_clk_sum = 0, st_clk_max = 0;
-
-    // Persistent wavefronts with XCD-aware work distribution: the tile grid is cut into 8 contiguous azimuth
-    // sectors, one queue per XCD (workgroup b is observed to run on XCD b % 8 -- used for L2 locality only, any
-    // placement is correct).  A wave drains its own XCD's queue first, then steals from the others.
-    unsigned q = blockIdx.x & 7u; int q_tried = 0;
-    for (;;) {
-        const int c0 = (int)(q * (unsigned)p.tiles_x) >> 3, c1 = (int)((q + 1u) * (unsigned)p.tiles_x) >> 3;
-        const unsigned nq = (unsigned)((c1 - c0) * p.tiles_y);
-        unsigned ti = 0;
-        if (lane == 0) ti = atomicAdd(p.tile_counter + q, 1u);
-        ti = __builtin_amdgcn_readfirstlane(ti);
-        if (ti >= nq) {
-            if (++q_tried == 8) break;
-            q = (q + 1u) & 7u;
-            continue;
-        }
-        const int ty = (int)(ti % (unsigned)p.tiles_y), tx = c0 + (int)(ti / (unsigned)p.tiles_y);
-        const unsigned long long clk0 = p.stats ? wall_clock64() : 0ull;
-        const int h = ty * TH + (lane >> p.tw_log2), w = (tx << p.tw_log2) + (lane & TWm);
-        const bool valid = (h < p.H) && (w < p.W);
-        const size_t r = valid ? ((size_t)h * p.W + w) : 0;
-        float o[3], d[3], inv[3];
-        for (int i = 0; i < 3; i++) { o[i] = p.ray_o[3 * r + i]; d[i] = p.ray_d[3 * r + i]; inv[i] = 1.0f / d[i]; }
-        float b[16];
-        lrt_sh_basis(p.deg, d, b);
-
-        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f, Wt = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-        float dL[LRT_NCH], fin[LRT_NCH], dL_dbg = 0.f;
-        if (BWD) {
-            for (int i = 0; i < LRT_NCH; i++) { dL[i] = p.dL_dout[LRT_NCH * r + i]; fin[i] = p.out9_in[LRT_NCH * r + i]; }
-            dL_dbg = dL[0] * bg0 + dL[1] * bg1 + dL[2] * bg2;
-        }
-        float base = __uint_as_float(__float_as_uint(LRT_T_NEAR) - 1u);   // accept t >= 0.2 (forward.cu:214)
-        bool done = !valid;
-        int dbg_n = 0, n_rec = 0;
-
-        for (int pass = 0; pass < 4096; ++pass) {   // hard bound (65k hits per ray) so a bug can never hang the GPU
-            const bool act = !done;
-            if (!__any(act)) break;
-            st_pass++;
-            // ---- per-lane 16-slot nearest-hit buffer (params.h:83-97), ascending in t
-            float kt[LRT_CHUNK], ka[LRT_CHUNK]; int kg[LRT_CHUNK];
-#pragma unroll
-            for (int i = 0; i < LRT_CHUNK; i++) { kt[i] = 1e16f; kg[i] = 0; ka[i] = 0.f; }
-            unsigned cnt = 0;
-
-            // ---- packet traversal; stack entry = (is_leaf << 31) | index, kept in lane sp of one VGPR
-            int stk = 0; int sp = 0;
-            sp = 1;                                                         // root = node 0 in lane 0 (stk == 0)
-            while (sp > 0) {
-                sp--;
-                const unsigned e = (unsigned)__builtin_amdgcn_readlane(stk, sp);
-                if (e & 0x80000000u) {
-                    // ---------------- leaf: every ray of the tile tests every quad of the leaf.
-                    // ONE coalesced 512-B vector load fetches the 8 records (lane L holds float4 #L%4 of quad L/4);
-                    // each record is then broadcast to SGPRs with v_readlane (one memory round trip per leaf, not per quad).
-                    const int k0 = (int)(e & 0x7fffffffu) * LRT_LEAF;
-                    float4 lv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (lane < 4 * LRT_LEAF) lv = reinterpret_cast<const float4*>(g_rec)[(size_t)k0 * 4 + lane];
-                    for (int j = 0; j < LRT_LEAF; ++j) {
-                        const int l0 = 4 * j;
-                        // staged test, cheapest rejection first; every stage ends in a wave-uniform early-out
-                        const float flim = rdl(lv.w, l0 + 1);
-                        if (!(flim > 0.f)) continue;                                    // unhittable / padding record
-                        st_prims++;
-                        const float nx = rdl(lv.x, l0), ny = rdl(lv.y, l0), nz = rdl(lv.z, l0);
-                        const float cx = rdl(lv.x, l0 + 1) - o[0], cy = rdl(lv.y, l0 + 1) - o[1], cz = rdl(lv.z, l0 + 1) - o[2];
-                        const float t = (nx * cx + ny * cy + nz * cz) / (nx * d[0] + ny * d[1] + nz * d[2]);
-                        bool hit = act && (t > base) && (t < kt[LRT_CHUNK - 1]);         // anyhit: forward.cu:323
-                        if (!__any(hit)) continue;
-                        const float px = t * d[0] - cx, py = t * d[1] - cy, pz = t * d[2] - cz;   // x - mu
-                        const float u = rdl(lv.x, l0 + 2) * px + rdl(lv.y, l0 + 2) * py + rdl(lv.z, l0 + 2) * pz;
-                        hit = hit && (fabsf(u) <= flim);
-                        if (!__any(hit)) continue;
-                        const float v = rdl(lv.x, l0 + 3) * px + rdl(lv.y, l0 + 3) * py + rdl(lv.z, l0 + 3) * pz;
-                        hit = hit && (fabsf(v) <= flim);
-                        if (__any(hit)) {
-                            st_ins++;
-                            if (hit) {
-                                cnt++;
-                                float ct = t, ca = rdl(lv.w, l0) * expf(-0.5f * (u * u + v * v));   // op * G, un-clamped
-                                int cg = __float_as_int(rdl(lv.w, l0 + 2));
-#pragma unroll
-                                for (int i = 0; i < LRT_CHUNK; i++) {                 // sorted insert, forward.cu:336-352
-                                    const bool sw = kt[i] > ct;
-                                    const float tt = kt[i], ta = ka[i]; const int tg = kg[i];
-                                    kt[i] = sw ? ct : tt; ka[i] = sw ? ca : ta; kg[i] = sw ? cg : tg;
-                                    ct = sw ? tt : ct; ca = sw ? ta : ca; cg = sw ? tg : cg;
-                                }
-                            }
-                        }
-                    }
-                } else {
-                    // ---------------- inner node: 8 child boxes (SoA), slab test per lane, ballot per child
-                    typedef float f16v __attribute__((ext_vector_type(16)));
-                    const f16v* ndv = static_cast<const f16v*>(__builtin_assume_aligned(g_nodes + (size_t)e * LRT_NODE_FLOATS, 256));
-                    const f16v nA = ndv[0], nB = ndv[1], nC = ndv[2];               // 3 x s_load_dwordx16: lo.x lo.y | lo.z hi.x | hi.y hi.z
-                    const float2 nH = *reinterpret_cast<const float2*>(g_nodes + (size_t)e * LRT_NODE_FLOATS + 48);
-                    float nd[48];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) { nd[i] = nA[i]; nd[16 + i] = nB[i]; nd[32 + i] = nC[i]; }
-                    const unsigned cbase = (unsigned)__float_as_int(nH.x);
-                    const unsigned cleaf = (unsigned)__float_as_int(nH.y) << 31;
-                    const float tfar = kt[LRT_CHUNK - 1];
-                    unsigned key[8]; int nh = 0;
-                    st_nodes++;
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float t0x = (nd[c] - o[0]) * inv[0], t1x = (nd[24 + c] - o[0]) * inv[0];
-                        const float t0y = (nd[8 + c] - o[1]) * inv[1], t1y = (nd[32 + c] - o[1]) * inv[1];
-                        const float t0z = (nd[16 + c] - o[2]) * inv[2], t1z = (nd[40 + c] - o[2]) * inv[2];
-                        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-                        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                        const bool hit = (p.no_cull & 1) ? (nd[c] < LRT_EMPTY) : (act && (tf >= fmaxf(tn, base)) && (tn <= tfar));
-                        const unsigned long long m = __ballot(hit);
-                        unsigned kk = 0xffffffffu;
-                        if (m) {
-                            const int first = __ffsll((long long)m) - 1;
-                            const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tn, 0.f)), first);
-                            kk = (p.no_cull & 2) ? (unsigned)c : ((kb & ~7u) | (unsigned)c);
-                            nh++;
-                        }
-                        key[c] = kk;
-                    }
-                    // sort the (distance | child) keys ascending: 19-comparator network, all wave-uniform
-                    CSWAP(key[0], key[1]); CSWAP(key[2], key[3]); CSWAP(key[4], key[5]); CSWAP(key[6], key[7]);
-                    CSWAP(key[0], key[2]); CSWAP(key[1], key[3]); CSWAP(key[4], key[6]); CSWAP(key[5], key[7]);
-                    CSWAP(key[1], key[2]); CSWAP(key[5], key[6]); CSWAP(key[0], key[4]); CSWAP(key[3], key[7]);
-                    CSWAP(key[1], key[5]); CSWAP(key[2], key[6]);
-                    CSWAP(key[1], key[4]); CSWAP(key[3], key[6]);
-                    CSWAP(key[2], key[4]); CSWAP(key[3], key[5]);
-                    CSWAP(key[3], key[4]);
-#pragma unroll
-                    for (int j = 7; j >= 0; j--) {                                    // farthest first -> nearest pops first
-                        if (j < nh) {
-                            const unsigned ent = cleaf | (cbase + (key[j] & 7u));
-                            stk = (lane == sp) ? (int)ent : stk;                    // v_writelane equivalent (uniform ent, sp)
-                            sp++;
-                        }
-                    }
-                }
-            }
-
-            // ---- stage the sorted chunk through LDS so the consume loop can be a real loop
-#pragma unroll
-            for (int i = 0; i < LRT_CHUNK; i++) { s_t[wv][i][lane] = kt[i]; s_g[wv][i][lane] = kg[i]; s_a[wv][i][lane] = ka[i]; }
-            const int nv = (int)min(cnt, (unsigned)LRT_CHUNK);
-            bool stop = false; float last_t = base;
-            for (int i = 0; i < LRT_CHUNK; ++i) {
-                const bool on = act && !stop && (i < nv);
-                if (!__any(on)) break;
-                if (on) {
-                    const float t = s_t[wv][i][lane]; const int g = s_g[wv][i][lane]; const float ao = s_a[wv][i][lane];
-                    last_t = t;
-                    if (p.dbg && dbg_n < 32) { p.dbg[r * 64 + 2 * dbg_n] = t; p.dbg[r * 64 + 2 * dbg_n + 1] = __int_as_float(g); dbg_n++; }
-                    st_cand++;
-                    const float alpha = fminf(LRT_ALPHA_MAX, ao);                       // forward.cu:247
-                    if (alpha >= LRT_ALPHA_MIN) {
-                        const float testT = T * (1.f - alpha);
-                        if (testT < LRT_T_STOP) {
-                            stop = true;                                                // forward.cu:253-257
-                        } else {
-                            const float wgt = alpha * T;
-                            st_comp++;
-                            if (!BWD) {
-                                float c0, c1, c2; bool cl0;
-                                sh_colour(p, g, b, nsh, c0, c1, c2, cl0);
-                                C0 += wgt * c0; C1 += wgt * c1; C2 += wgt * c2;
-                                Dd += wgt * t; Wt += wgt;
-                                unsafeAtomicAdd(p.accum + g, wgt);                      // forward.cu:268
-                                if (p.hit_t) {                                          // record for the replay backward
-                                    if (n_rec < p.hit_cap) {
-                                        const size_t id = r * (size_t)p.hit_cap + n_rec;
-                                        p.hit_t[id] = t; p.hit_g[id] = g;
-                                    }
-                                    n_rec++;
-                                }
-                            } else {
-                                RayAcc a = {T, C0, C1, C2, Dd, Wt, N0, N1, N2};
-                                bwd_hit<true, true>(p, o, d, b, nsh, dL, fin, dL_dbg, t, g, ao, a);
-                                C0 = a.C0; C1 = a.C1; C2 = a.C2; Dd = a.Dd; N0 = a.N0; N1 = a.N1; N2 = a.N2;
-                            }
-                            T = testT;
-                        }
-                    }
-                }
-            }
-            if (act) {
-                if (stop || cnt < (unsigned)LRT_CHUNK) done = true;                      // forward.cu:282-285
-                else base = last_t + LRT_STEP_EPS;                                      // forward.cu:288
-            }
-        }
-
-        if (p.stats) { const unsigned long long dc = wall_clock64() - clk0; st_clk_sum += dc; st_clk_max = dc > st_clk_max ? dc : st_clk_max; }
-        if (!BWD && valid && p.hit_t) {
-            p.hit_n[r] = min(n_rec, p.hit_cap); if (n_rec > p.hit_cap) atomicOr(p.hit_ovf, 1);
-            if (p.hit_count) atomicAdd(p.hit_count, (unsigned)min(n_rec, p.hit_cap));     // no return value: fire and forget
-        }
-        if (!BWD && valid) {
-            float* op_ = p.out9 + LRT_NCH * r;
-            op_[0] = C0 + T * bg0; op_[1] = C1 + T * bg1; op_[2] = C2 + T * bg2;
-            op_[3] = Dd; op_[4] = Wt; op_[5] = 0.f; op_[6] = 0.f; op_[7] = 0.f; op_[8] = T;
-        }
-    }
-    if (p.stats) {
-        if (lane == 0) { atomicAdd(p.stats + 5, st_clk_sum); atomicMax(p.stats + 6, st_clk_max); atomicAdd(p.stats + 7, (unsigned long long)st_ins); }
-        const unsigned a = wave_sum_u(st_cand), c = wave_sum_u(st_comp);
-        if (lane == 0) {
-            atomicAdd(p.stats + 0, (unsigned long long)a); atomicAdd(p.stats + 1, (unsigned long long)c);
-            atomicAdd(p.stats + 2, (unsigned long long)st_pass); atomicAdd(p.stats + 3, (unsigned long long)st_nodes);
-            atomicAdd(p.stats + 4, (unsigned long long)st_prims);
-        }
-    }
-}
+#include "lrt_trace_legacy.inc"
 
 #include "lrt_collect.inc"
 #include "lrt_collect4.inc"
