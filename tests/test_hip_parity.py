@@ -67,6 +67,22 @@ def test_s10k_forward_backward_match_oracle(s10k, mode, deg, bg):
         assert np.all(h["grads"]["shs"][:, (deg + 1) ** 2:, :] == 0)           # inactive SH bands get no gradient
 
 
+@pytest.mark.parametrize("M,deg", [(1, 0), (4, 1), (9, 2), (16, 1)])
+def test_sh_tables_narrower_than_16(s10k, M, deg):
+    """shs (P, M, 3) with M < 16 (a model that has not reached SH degree 3, or never will): the row stride of the SH table
+    and of its gradient is M, and only (deg+1)^2 <= M coefficients are read / written."""
+    sc, o, d, dL = s10k
+    sc = dict(sc); sc["shs"] = np.ascontiguousarray(sc["shs"][:, :M])
+    fw, bw = oracle_run(sc, o, d, deg, scenes.BG_DEFAULT, dL)
+    h = run_hip(sc, o, d, deg, scenes.BG_DEFAULT, dL)
+    assert rel_l2(h["out"], fw["out"]) < 1e-5 and frac_outside(h["out"], fw["out"], 1e-4) <= 1e-3
+    assert h["grads"]["shs"].shape == (sc["means"].shape[0], M, 3)
+    for k in GRADS:
+        assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 1e-3, k
+    if (deg + 1) ** 2 < M:                                                     # coefficients above the active degree get no gradient
+        assert not np.any(h["grads"]["shs"][:, (deg + 1) ** 2:])
+
+
 def test_committed_golden_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "s10k_golden.npz"))
     sc, o, d = scenes.s10k()
