@@ -83,6 +83,34 @@ def test_sh_tables_narrower_than_16(s10k, M, deg):
         assert not np.any(h["grads"]["shs"][:, (deg + 1) ** 2:])
 
 
+def test_side_stream(s10k):
+    """Everything the library enqueues (kernels, rocPRIM sorts, fills, the pinned flag copy) goes to the caller's current
+    stream: build + forward + backward issued on a side stream give the default-stream results."""
+    from tests.hip_util import settings, DEFAULT_OPTS
+    sc, o, d, dL = s10k
+    ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    side = torch.cuda.Stream(device="cuda:0")
+    tr = Tracer()
+    for k, v in DEFAULT_OPTS.items():
+        tr.optix_context.set_option(k, v)
+    t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in sc.items()}
+    ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")
+    g = torch.as_tensor(dL, device="cuda:0")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for v in t.values():
+                v.grad = None
+            tr.build_from_gaussians(t["means"], t["scales"], t["rotations"], t["opacities"])
+            out, _ = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"],
+                        scales=t["scales"], rotations=t["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+            out.backward(g)
+    side.synchronize()
+    assert rel_l2(out.detach().cpu().numpy(), ref["out"]) < 1e-6
+    for k in GRADS:
+        assert rel_l2(t[k].grad.cpu().numpy(), ref["grads"][k]) < 1e-5, k
+
+
 def test_committed_golden_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "s10k_golden.npz"))
     sc, o, d = scenes.s10k()
