@@ -33,40 +33,16 @@ def read(which, n, dtype):
 cap = 1024
 hit_n = read(5, H * W, np.int32); hit_t = read(6, H * W * cap, np.float32).reshape(H * W, cap); hit_g = read(7, H * W * cap, np.int32).reshape(H * W, cap)
 
-# ---- brute force: all quads of one ray (float64), lrt_math.h record semantics
-mu = sc["means"].astype(np.float64); s2 = sc["scales"].astype(np.float64); q = sc["rotations"].astype(np.float64); op = sc["opacities"].astype(np.float64).reshape(-1)
-q = q / np.linalg.norm(q, axis=1, keepdims=True)
-w_, x_, y_, z_ = q.T
-R = np.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - w_ * z_), 2 * (x_ * z_ + w_ * y_),
-              2 * (x_ * y_ + w_ * z_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - w_ * x_),
-              2 * (x_ * z_ - w_ * y_), 2 * (y_ * z_ + w_ * x_), 1 - 2 * (x_ * x_ + y_ * y_)], 1).reshape(-1, 3, 3)
-n_ = R[:, :, 2]; U = R[:, :, 0] / s2[:, :1]; V = R[:, :, 1] / s2[:, 1:2]
-flim = np.where(op > 1 / 255, np.sqrt(2 * np.log(np.maximum(255 * op, 1.0000001))) + 0.01, -1.0)
+# ---- brute force: all quads of one ray (float64), own intersection code, no tree (oracle/bruteforce.py)
+from oracle.bruteforce import QuadScene, raygen_loop
+qs = QuadScene(sc["means"], sc["scales"], sc["rotations"], sc["opacities"])
+ray_candidates = qs.candidates
 
-def ray_candidates(oo, dd):
-    den = n_ @ dd
-    tt = ((mu - oo) * n_).sum(1) / den
-    p = oo + tt[:, None] * dd - mu
-    u = (U * p).sum(1); v = (V * p).sum(1)
-    hit = (np.abs(u) <= flim) & (np.abs(v) <= flim) & (tt > 0) & np.isfinite(tt)
-    g = np.nonzero(hit)[0]
-    order = np.argsort(tt[g], kind="stable")
-    g = g[order]
-    return g, tt[g], np.minimum(0.99, op[g] * np.exp(-0.5 * (u[g] ** 2 + v[g] ** 2)))
 
 def reference_loop(g, tt, al):
-    comp = []; T = 1.0; start = -1.0; i = 0; drops = []
-    while True:
-        while i < len(g) and not (tt[i] > start): drops.append((int(g[i]), float(tt[i]))); i += 1
-        chunk = list(range(i, min(i + 16, len(g)))); i += len(chunk)
-        stop = False
-        for k in chunk:
-            if tt[k] < 0.2 or al[k] < 1 / 255: continue
-            if T * (1 - al[k]) < 1e-4: stop = True; break
-            comp.append((int(g[k]), float(tt[k]))); T *= 1 - al[k]
-        if stop or len(chunk) < 16: break
-        start = tt[chunk[-1]] + 1e-5
-    return comp, drops
+    comp, _, _, drops = raygen_loop(g, tt, al)
+    return [(c[0], c[1]) for c in comp], drops
+
 
 err = np.abs(out - fw["out"]).reshape(-1, 9).max(1)
 bad = np.argsort(-err)[:4]
