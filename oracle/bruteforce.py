@@ -59,3 +59,29 @@ def raygen_loop(g, t, alpha):
             break
         start = t[chunk[-1]] + 1e-5
     return comp, T, consumed, drops
+
+
+_C0 = 0.28209479177387814
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def sh_colour(sh, direction, deg: int):
+    """Colour of one Gaussian seen along `direction` (any length): real SH up to degree 3 in the 3DGS convention
+    (lib/utils/sh_utils.py:58-113) + 0.5, channel 0 clamped at zero (forward.cu:67-111).  sh (M,3)."""
+    d = np.asarray(direction, np.float64); x, y, z = d / np.linalg.norm(d)
+    b = [_C0]
+    if deg > 0:
+        b += [-_C1 * y, _C1 * z, -_C1 * x]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        b += [_C2[0] * xy, _C2[1] * yz, _C2[2] * (2 * zz - xx - yy), _C2[3] * xz, _C2[4] * (xx - yy)]
+    if deg > 2:
+        b += [_C3[0] * y * (3 * xx - yy), _C3[1] * xy * z, _C3[2] * y * (4 * zz - xx - yy), _C3[3] * z * (2 * zz - 3 * xx - 3 * yy),
+              _C3[4] * x * (4 * zz - xx - yy), _C3[5] * z * (xx - yy), _C3[6] * x * (xx - 3 * yy)]
+    n = min(len(b), sh.shape[0])
+    c = (np.asarray(b[:n])[:, None] * np.asarray(sh, np.float64)[:n]).sum(0) + 0.5
+    c[0] = max(c[0], 0.0)
+    return c

@@ -5,7 +5,7 @@ import numpy as np
 
 from lidar_rt_amd import scenes
 from oracle import oracle
-from oracle.bruteforce import QuadScene, raygen_loop
+from oracle.bruteforce import QuadScene, raygen_loop, sh_colour
 
 
 def test_oracle_matches_brute_force_raygen_loop_on_the_dense_scene():
@@ -27,6 +27,10 @@ def test_oracle_matches_brute_force_raygen_loop_on_the_dense_scene():
         px = fw["out"].reshape(-1, 9)[r]
         assert abs(px[3] - depth) <= 1e-9 * max(1.0, abs(depth)) and abs(px[4] - weight) <= 1e-9, r      # depth, accumulated weight
         assert abs(px[8] - T) <= 1e-12, r                                                             # final transmittance
+        if r % 8 == 0:                                                                                # colour = sum w c + T bg (every 8th ray: ~100 SH evaluations each)
+            col = sum(w * sh_colour(sc["shs"][gi], d.reshape(-1, 3)[r], 3) for gi, _, w in comp) + T * np.asarray(scenes.BG_DEFAULT, np.float64)
+            np.testing.assert_allclose(px[:3], col, rtol=1e-9, atol=1e-12)
+            assert px[5] == px[6] == px[7] == 0.0
         for gi, _, w in comp:
             accum[gi] += w
     assert n_drop_rays >= 1                                       # the scene does exercise the restart epsilon
