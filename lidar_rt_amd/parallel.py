@@ -123,8 +123,7 @@ class ShardedTracer:
         wmax = max(column_slab(W, r, self.world)[1] - column_slab(W, r, self.world)[0] for r in range(self.world))
         pad = torch.zeros((H, wmax, 9), dtype=out_loc.dtype, device=out_loc.device)
         pad[:, :b - a] = out_loc
-        parts = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(parts, pad, group=self.group)
+        parts = self._all_gather_rows(pad)               # one flat receive buffer with RCCL
         cols = []
         for r in range(self.world):
             ra, rb = column_slab(W, r, self.world)
