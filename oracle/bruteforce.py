@@ -2,7 +2,7 @@
 loop for ONE ray -- every quad of the scene is intersected (no BVH), the hits are sorted, and the 16-candidate chunk loop
 with its restart at t16 + 1e-5 is replayed (forward.cu:146-308 as restated in oracle/lrt_oracle_impl.inc; quad extent of
 lib/utils/primitive_utils.py:182-224).  It shares no code with the C oracle (own intersection, no tree, float64), so the two
-pin each other: tests/test_oracle_bruteforce.py; tools/dense_arbiter.py uses it to arbitrate HIP-vs-oracle differences."""
+pin each other: tests/test_oracle_bruteforce.py; tests/tools/dense_arbiter.py uses it to arbitrate HIP-vs-oracle differences."""
 import numpy as np
 
 

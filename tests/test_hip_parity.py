@@ -328,7 +328,7 @@ def test_dense_translucent_scene_overflows_every_capacity_once():
                        **{k: t[k].grad.cpu().numpy() for k in GRADS}})
     assert [f["cap"] for f in frames] == [512, 512, 512]
     # ~100 hits per ray a few mm apart and a chunk boundary every 16: here and there two candidates straddle the reference's
-    # restart epsilon (t16 + 1e-5) within float32 rounding (tools/dense_arbiter.py shows one such ray: 1.0e-5 apart at a
+    # restart epsilon (t16 + 1e-5) within float32 rounding (tests/tools/dense_arbiter.py shows one such ray: 1.0e-5 apart at a
     # boundary), and implementations with other FMA contractions decide differently -> one hit, i.e. up to a few per cent of
     # one ray.  Hence statistical bounds, as for the large scenes.
     assert rel_l2(frames[0]["out"], fw["out"]) < 1e-3 and frac_outside(frames[0]["out"], fw["out"], 1e-4) <= 2e-2

@@ -5,7 +5,7 @@ sorted; chunks of 16 with the restart at t16 + 1e-5; forward.cu:146-308 as resta
 compared with the hit record of the HIP forward and with the oracle's counts."""
 import os, sys, ctypes as C
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes
 from lidar_rt_amd.diff_lidar_tracer import Tracer
 from tests.test_hip_parity import oracle_run

@@ -2,7 +2,7 @@
 """Developer tool: the dense translucent scene of tests/test_hip_parity.py through every forward mode, against the oracle."""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes
 from tests.test_hip_parity import oracle_run
 from tests.hip_util import run_hip, rel_l2

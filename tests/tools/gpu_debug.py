@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes, _capi                              # noqa: E402
 from lidar_rt_amd.diff_lidar_tracer import Tracer                   # noqa: E402
