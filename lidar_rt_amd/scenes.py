@@ -198,3 +198,148 @@ def dense_translucent(P: int = 25000, seed: int = 21, H: int = 4, W: int = 48):
     reach = 0.3 + 2.1 * 1.4143 * sc["scales"].max(1)              # half diagonal of the quad at opacity 0.03 (2.02 sigma)
     keep = np.linalg.norm(sc["means"] - o.reshape(-1, 3)[0], axis=1) > reach
     return {k: np.ascontiguousarray(v[keep]) for k, v in sc.items()}, o, d
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Dataset-shaped synthetic frames for BASELINE configs[2..4]: the range-image geometry of the two
+# datasets the reference trains on -- the data themselves are not available here.
+#   Waymo top LiDAR : 64 beams x 2650 columns, per-beam inclination table, 0.5-pixel offsets, sensor-to-ego yaw
+#                     (lib/dataloader/waymo_loader/__init__.py:36-131, lib/scene/lidar_sensor.py:395-434)
+#   KITTI-360 HDL-64: 66 x 1030 range image, inclination interpolated in (-24.9, 2.0) degrees
+#                     (lib/dataloader/kitti_loader/__init__.py:186-187)
+WAYMO_HW = (64, 2650)
+KITTI360_HW = (66, 1030)
+
+
+def waymo_inclinations(H: int = 64) -> np.ndarray:
+    """A per-beam inclination table shaped like the Waymo top LiDAR's: -17.6 .. +2.4 degrees, beams packed more densely
+    towards the horizon (ascending, radians, float32; the sensor model flips it so that row 0 is the highest beam)."""
+    u = np.linspace(0.0, 1.0, H)
+    deg = -17.6 + 20.0 * (0.35 * u + 0.65 * np.sqrt(u))
+    return np.radians(deg).astype(np.float32)
+
+
+def pose_matrix(t, yaw=0.0, pitch=0.0, roll=0.0) -> np.ndarray:
+    """4x4 float32 rigid transform from a translation and z-y-x Euler angles (radians)."""
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    R = np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                  [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                  [-sp, cp * sr, cp * cr]])
+    m = np.eye(4)
+    m[:3, :3] = R; m[:3, 3] = np.asarray(t, np.float64)
+    return m.astype(np.float32)
+
+
+def range_rays(H: int, W: int, inclination, sensor2world: np.ndarray, data_type: str = "KITTI",
+               sensor2ego: np.ndarray = None) -> Tuple[np.ndarray, np.ndarray]:
+    """numpy float32 restatement of ``LiDARSensor.get_range_rays`` (lib/scene/lidar_sensor.py:395-434) for both dataset
+    modes; the torch version the training loop uses is ``training.RangeFrames.range_rays`` (pinned against the
+    reference's golden grids) and ``tests/test_config_shapes_gpu.py`` checks the two against each other."""
+    f = np.float32
+    waymo = data_type == "Waymo"
+    off = f(0.5) if waymo else f(0.0)
+    yaw = f(math.atan2(float(sensor2ego[1, 0]), float(sensor2ego[0, 0]))) if waymo else f(0.0)
+    x = (np.arange(W, 0, -1, dtype=f) - off) / f(W)
+    az = (x * f(2.0) * f(np.pi) - f(np.pi) - yaw)[None, :].astype(f)
+    inc = np.asarray(inclination, f).reshape(-1)
+    if inc.size == 2:
+        y = (np.arange(H, 0, -1, dtype=f) - off) / f(H)
+        incl = (y * (inc[1] - inc[0]) + inc[0])[:, None].astype(f)
+    else:
+        incl = inc[::-1][:, None].astype(f)
+    d = np.stack([np.cos(incl) * np.cos(az), np.cos(incl) * np.sin(az), np.sin(incl) * np.ones_like(az)], -1).astype(f)
+    d = (d @ sensor2world[:3, :3].T.astype(f)).astype(f)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True).astype(f)
+    o = np.broadcast_to(sensor2world[:3, 3].astype(f), (H, W, 3)).copy()
+    return o, np.ascontiguousarray(d, dtype=f)
+
+
+def waymo_frame(P: int = 2_000_000, seed: int = SEED + 7, radius_scale: float = 1.25, frame: int = 0):
+    """BASELINE configs[2] shape: a static scene of ~2 M background Gaussians seen by a Waymo-style top LiDAR (64 x 2650,
+    per-beam inclinations, posed sensor).  The sensor sits 0.45 m above the scene generator's origin and moves 0.8 m per frame;
+    every Gaussian centre stays > 1.5 m away from it.  Returns (scene, ray_o, ray_d)."""
+    sc = make_scene(P, seed=seed, radius_scale=radius_scale)
+    o, d = waymo_sensor_rays(frame)
+    return sc, o, d
+
+
+def waymo_sensor_rays(frame: int = 0):
+    """The 64 x 2650 ray grid of the synthetic Waymo-style sensor at `frame` (0.8 m forward and a little yaw per frame)."""
+    H, W = WAYMO_HW
+    s2w = pose_matrix((0.8 * frame, 0.1 * frame, 0.45), yaw=0.03 * frame + 0.4, pitch=0.01, roll=-0.008)
+    s2e = pose_matrix((1.43, 0.0, 2.18), yaw=0.02)
+    return range_rays(H, W, waymo_inclinations(H), s2w, "Waymo", s2e)
+
+
+def actor_asset(n: int, rng, size=(4.4, 1.9, 1.6)) -> Dict[str, np.ndarray]:
+    """Gaussians on the surface of a car-sized box in the ACTOR frame (what the reference keeps per rigid object,
+    lib/scene/gaussian_model.py:129-134): means (n,3), scales, rotations (local), opacities, shs."""
+    sx, sy, sz = size
+    face = rng.integers(0, 5, n)                                   # 4 sides + roof
+    u, v = rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)
+    p = np.zeros((n, 3)); nrm = np.zeros((n, 3))
+    for f_, (ax, sgn) in enumerate(((0, 1), (0, -1), (1, 1), (1, -1), (2, 1))):
+        m = face == f_
+        a1, a2 = [a for a in range(3) if a != ax]
+        p[m, ax] = sgn * 0.5 * size[ax]; p[m, a1] = u[m] * size[a1]; p[m, a2] = v[m] * size[a2]
+        nrm[m, ax] = sgn
+    p[:, 2] += 0.5 * sz
+    nrm += rng.normal(0, 0.05, (n, 3))
+    scales = np.exp(rng.uniform(np.log(0.03), np.log(0.15), (n, 2)))
+    rot = _frame_quaternions(nrm, rng.uniform(0, 2 * np.pi, n))
+    opac = np.clip(1.0 / (1.0 + np.exp(-rng.normal(0.5, 1.5, (n, 1)))), 0.02, 0.98)
+    shs = (rng.standard_normal((n, 16, 3)) * 0.02).astype(np.float32)
+    rgb = np.stack([rng.uniform(0, 1, n), np.ones(n), np.zeros(n)], 1)
+    shs[:, 0, :] = ((rgb - 0.5) / SH_C0).astype(np.float32)
+    return {"means": p.astype(np.float32), "scales": scales.astype(np.float32), "rotations": rot.astype(np.float32),
+            "opacities": opac.astype(np.float32), "shs": shs}
+
+
+def kitti360_dynamic(P_bg: int = 500_000, n_actors: int = 8, per_actor: int = 8000, seed: int = SEED + 11):
+    """BASELINE configs[3] shape: background Gaussians + ``n_actors`` rigid actor sets with a pose per frame, seen through
+    a 66 x 1030 KITTI-360 range image.  Returns (background scene, [actor assets], poses(frame) -> [(t (3,), q (4,))],
+    rays(frame) -> (ray_o, ray_d)).  Actors drive on circles of 6..30 m radius around the sensor, which itself advances
+    0.5 m per frame; nothing comes within 2 m of it."""
+    rng = np.random.default_rng(seed)
+    bg = make_scene(P_bg, seed=seed, radius_scale=1.0)
+    actors = [actor_asset(per_actor, rng) for _ in range(n_actors)]
+    rad = rng.uniform(6.0, 30.0, n_actors); ph0 = rng.uniform(0, 2 * np.pi, n_actors); om = rng.uniform(-0.04, 0.04, n_actors)
+
+    def poses(frame: int):
+        out = []
+        for a in range(n_actors):
+            ph = ph0[a] + om[a] * frame
+            t = np.array([rad[a] * np.cos(ph) + 0.5 * frame, rad[a] * np.sin(ph), GROUND_Z], np.float32)
+            yaw = ph + np.pi / 2
+            q = np.array([np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)], np.float32) * np.float32(1.0 + 0.3 * a)   # un-normalised
+            out.append((t, q))
+        return out
+
+    def rays(frame: int):
+        H, W = KITTI360_HW
+        s2w = pose_matrix((0.5 * frame, 0.0, 0.0), yaw=0.01 * frame)
+        return range_rays(H, W, (math.radians(-24.9), math.radians(2.0)), s2w, "KITTI")
+    return bg, actors, poses, rays
+
+
+def waymo_dynamic_4m(P_bg: int = 3_900_000, n_actors: int = 10, per_actor: int = 10_000, seed: int = SEED + 13, frame: int = 0):
+    """BASELINE configs[4] shape: ~4 M Gaussians (background + actors already posed into the world) under the Waymo grid.
+    Returns (scene, ray_o, ray_d); the scene spans 1.5x the S1M radius."""
+    rng = np.random.default_rng(seed)
+    sc = make_scene(P_bg, seed=seed, radius_scale=1.5)
+    parts = [sc]
+    for a in range(n_actors):
+        A = actor_asset(per_actor, rng)
+        r, ph = rng.uniform(8.0, 60.0), rng.uniform(0, 2 * np.pi)
+        yaw = ph + np.pi / 2
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        A["means"] = (A["means"].astype(np.float64) @ R.T + np.array([r * np.cos(ph), r * np.sin(ph), GROUND_Z])).astype(np.float32)
+        qa = np.array([np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)])
+        ql = A["rotations"].astype(np.float64)
+        A["rotations"] = np.stack([qa[0] * ql[:, 0] - qa[3] * ql[:, 3], qa[0] * ql[:, 1] - qa[3] * ql[:, 2],
+                                   qa[0] * ql[:, 2] + qa[3] * ql[:, 1], qa[0] * ql[:, 3] + qa[3] * ql[:, 0]], 1).astype(np.float32)
+        parts.append(A)
+    scene = {k: np.ascontiguousarray(np.concatenate([p[k] for p in parts], 0)) for k in sc}
+    o, d = waymo_sensor_rays(frame)
+    return scene, o, d

@@ -45,3 +45,80 @@ def frac_outside(a, b, rtol, floor=1e-3):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     scale = max(np.abs(b).max(), 1e-300)
     return float((np.abs(a - b) > rtol * np.maximum(np.abs(b), floor * scale)).mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Quantitative parity: the HIP path against the fp32 oracle, bounded by k x the algorithm's own noise floor (the fp32 oracle
+# against the fp64 oracle on the same inputs), and the measured numbers written to gpurun_out/parity/<name>.json
+# (tools/collect_parity.py turns those files into profiles/r02_parity.json = BASELINE.md section 6).
+# Why k = 4 and not 1: two float32 implementations differ from EACH OTHER by about twice what one of them differs from the
+# fp64 result, and the differences are threshold events, not rounding noise: hits less than ~2 ulp(t) apart change places
+# (only the colour channels see it), and a candidate on the edge of the reference's restart epsilon (t16 + 1e-5) is dropped by
+# one implementation and kept by the other.  tests/tools/outlier_arbiter.py arbitrates such rays hit by hit against a
+# brute-force float64 restatement of the raygen loop (27 of 40 examined rays: permutations of hits 0.3..5e-6 m apart, 13:
+# restart-epsilon edges); tests/tools/t_noise_probe.py measures the hit distance itself: 0.52 ulp median error for the HIP
+# path, 0.65 ulp for a float32 Moeller-Trumbore evaluation.  Measured ratios to the floor: 1..3.5 (profiles/r02_parity.json).
+FLOOR_K = 4.0            # on the fraction of elements beyond the tolerance (a count of events: robust)
+FLOOR_K_L2 = 8.0         # on the relative L2 error (dominated by the one or two largest events of an image: heavy-tailed)
+OUT_TOL, GRAD_TOL = 1e-4, 1e-3            # BASELINE.json north_star: 1e-4 relative on rendered channels, 1e-3 on gradients
+
+
+def parity_stats(got, ref, rtol, floor=1e-3):
+    """max / p99 of the element-wise relative error (relative to max(|ref|, floor * max|ref|)), the fraction of elements
+    beyond rtol, and the relative L2 error."""
+    a = np.asarray(got, np.float64).reshape(-1); b = np.asarray(ref, np.float64).reshape(-1)
+    if a.size == 0:
+        return {"max_rel": 0.0, "p99_rel": 0.0, "frac_gt_tol": 0.0, "rel_l2": 0.0, "tol": rtol, "n": 0}
+    scale = max(np.abs(b).max(), 1e-300)
+    e = np.abs(a - b) / np.maximum(np.abs(b), floor * scale)
+    return {"max_rel": float(e.max()), "p99_rel": float(np.quantile(e, 0.99)), "frac_gt_tol": float((e > rtol).mean()),
+            "rel_l2": float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)), "tol": rtol, "n": int(a.size)}
+
+
+OUT_CHANNELS = ((0, "intensity"), (1, "rayhit"), (2, "raydrop"), (3, "depth"), (4, "weight"), (8, "transmittance"))
+
+
+def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations", "opacities", "shs"), extra=None, k=FLOOR_K, check=True):
+    """Compare hip = {"out", "accum", "grads": {...}} with the fp32 oracle results f32 = (fw, bw) and, when the fp64 oracle
+    results are given, assert every statistic within k x the f32-vs-f64 floor (or within the north-star tolerance itself where
+    the floor is below it).  Writes the table to gpurun_out/parity/<name>.json and returns it."""
+    import json, os
+    fw, bw = f32
+    rows = {}
+
+    def add(label, got, ref, tol, ref64=None):
+        st = parity_stats(got, ref, tol)
+        if ref64 is not None:
+            fl = parity_stats(ref, ref64, tol)
+            st["floor"] = {q: fl[q] for q in ("max_rel", "p99_rel", "frac_gt_tol", "rel_l2")}
+            h64 = parity_stats(got, ref64, tol)                    # the HIP path against the fp64 oracle, for the record
+            st["vs_f64"] = {q: h64[q] for q in ("max_rel", "p99_rel", "frac_gt_tol", "rel_l2")}
+        rows[label] = st
+
+    for c, cname in OUT_CHANNELS:
+        add(f"out.{cname}", hip["out"][..., c], fw["out"][..., c], OUT_TOL, None if f64 is None else f64[0]["out"][..., c])
+    add("accum", hip["accum"], fw["accum"], OUT_TOL, None if f64 is None else f64[0]["accum"])
+    if bw is not None and "grads" in hip:
+        for g in grads:
+            add(f"grad.{g}", hip["grads"][g].reshape(bw[g].shape), bw[g], GRAD_TOL, None if f64 is None else f64[1][g])
+    rep = {"name": name, "k_frac": k, "k_l2": k * (FLOOR_K_L2 / FLOOR_K), "asserted": bool(check), "rows": rows, **(extra or {})}
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
+    bad = []
+    for label, st in rows.items():
+        if "floor" not in st:
+            continue
+        tol = st["tol"]
+        # a statistic passes when it is within k x the floor; where the floor itself is far below the north-star tolerance
+        # (small scenes) being within that tolerance is enough
+        if st["frac_gt_tol"] > max(k * st["floor"]["frac_gt_tol"], 1e-3 if tol == OUT_TOL else 2e-3):
+            bad.append((label, "frac_gt_tol", st["frac_gt_tol"], st["floor"]["frac_gt_tol"]))
+        if st["rel_l2"] > max(k * (FLOOR_K_L2 / FLOOR_K) * st["floor"]["rel_l2"], 2 * tol):
+            bad.append((label, "rel_l2", st["rel_l2"], st["floor"]["rel_l2"]))
+    assert not (check and bad), f"{name}: beyond {k} x the f32-vs-f64 floor: {bad}"
+    return rep

@@ -21,7 +21,7 @@ from lidar_rt_amd.diff_lidar_tracer import Tracer
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.hip_util import run_hip, rel_l2, frac_outside
+    from tests.hip_util import run_hip, rel_l2, frac_outside, parity_report
 
 MODES = [{"fwd_mode": 1, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 1, "bwd_mode": 1, "defer_colour": 0},
          {"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2},
@@ -214,21 +214,11 @@ def test_s200k_matches_oracle_within_noise_floor():
     sc = scenes.make_scene(200_000, radius_scale=0.5)
     o, d = scenes.kitti_rays(32, 512)
     dL = scenes.upstream_grad(32, 512)
-    fw, bw = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
-    fw64, bw64 = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL, prec="f64")
+    f32 = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    f64 = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL, prec="f64")
     h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
-    floor_frac = frac_outside(fw["out"], fw64["out"], 1e-4)
-    print(f"S200k out: frac>1e-4 hip-vs-f32oracle {frac_outside(h['out'], fw['out'], 1e-4):.2e}, "
-          f"f32oracle-vs-f64oracle (noise floor) {floor_frac:.2e}; L2 {rel_l2(h['out'], fw['out']):.2e}")
-    assert frac_outside(h["out"], fw["out"], 1e-4) <= max(5e-3, 3 * floor_frac)
-    assert rel_l2(h["out"], fw["out"]) < 2e-3
-    assert frac_outside(h["out"], fw["out"], 5e-2) <= 2e-4                     # no gross outliers
-    for k in GRADS:
-        ref = bw[k]; got = h["grads"][k].reshape(ref.shape)
-        floor = rel_l2(bw[k], bw64[k])
-        print(f"S200k d_{k}: L2 hip-vs-f32 {rel_l2(got, ref):.2e}, f32-vs-f64 floor {floor:.2e}, frac>1e-3 {frac_outside(got, ref, 1e-3):.2e}")
-        assert frac_outside(got, ref, 1e-3) <= 2e-2
-        assert rel_l2(got, ref) < max(2e-2, 3 * floor)
+    assert frac_outside(h["out"], f32[0]["out"], 5e-2) <= 2e-4                 # no gross outliers
+    parity_report("s200k", h, f32, f64, extra={"config": "S200k: 200,000 Gaussians, 32x512 rays", "rays": [32, 512], "gaussians": 200_000})
 
 
 def test_s1m_full_size_parity_and_invariants(golden_dir):
@@ -245,13 +235,11 @@ def test_s1m_full_size_parity_and_invariants(golden_dir):
     # accum is the transpose-sum of the same weights
     np.testing.assert_allclose(h["accum"].sum(dtype=np.float64), h["out"][..., 4].sum(dtype=np.float64), rtol=1e-5)
     fw, bw = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
-    assert frac_outside(h["out"], fw["out"], 1e-4) <= 5e-3
-    assert frac_outside(h["out"], fw["out"], 5e-2) <= 2e-4
-    assert rel_l2(h["out"], fw["out"]) < 2e-3
-    for k in GRADS:
-        ref = bw[k]; got = h["grads"][k].reshape(ref.shape)
-        print(f"S1M d_{k}: L2 {rel_l2(got, ref):.2e} frac>1e-3 {frac_outside(got, ref, 1e-3):.2e}")
-        assert frac_outside(got, ref, 1e-3) <= 2e-2 and rel_l2(got, ref) < 2e-2
+    f64 = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL, prec="f64")
+    assert frac_outside(h["out"], fw["out"], 5e-2) <= 2e-4                     # no gross outliers
+    # every channel and every gradient within k x the fp32-vs-fp64 oracle floor (tests/hip_util.py: FLOOR_K); numbers -> gpurun_out/parity/s1m.json
+    parity_report("s1m", h, (fw, bw), f64, extra={"config": "BASELINE configs[1]: S1M, 1,000,000 Gaussians, 64x2048 rays", "rays": [H, W],
+                                                  "gaussians": 1_000_000, "C_mean": float(fw["n_cand"].mean()), "K_mean": float(fw["n_comp"].mean())})
     # permutation invariance: the input order of the Gaussians must not matter
     perm = np.random.default_rng(0).permutation(sc["means"].shape[0])
     scp = {k: np.ascontiguousarray(v[perm]) for k, v in sc.items()}
@@ -332,6 +320,11 @@ def test_dense_translucent_scene_overflows_every_capacity_once():
     # boundary), and implementations with other FMA contractions decide differently -> one hit, i.e. up to a few per cent of
     # one ray.  Hence statistical bounds, as for the large scenes.
     assert rel_l2(frames[0]["out"], fw["out"]) < 1e-3 and frac_outside(frames[0]["out"], fw["out"], 1e-4) <= 2e-2
+    f64 = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL, prec="f64")
+    # recorded, not asserted against the floor: 192 rays, one ray is 5e-3 of the image (the knife-edge ray described above)
+    parity_report("dense_translucent", {"out": frames[2]["out"], "accum": fw["accum"], "grads": {k: frames[2][k] for k in GRADS}}, (fw, bw), f64, check=False,
+                  extra={"config": "dense translucent stress scene: 192 rays, ~130 candidates / ~100 composited hits per ray (up to ~600 / ~500)",
+                         "rays": [4, 48], "gaussians": int(sc["means"].shape[0]), "note": "accum row = oracle against itself (not captured per frame)"})
     for k in GRADS:
         ref = bw[k]
         for f in frames:
