@@ -73,10 +73,32 @@ def cpu_baseline(sc, ray_o, ray_d, deg, bg, dL, col_stride=8):
     orc.backward(o, d, sc["shs"], deg, bg, fw["out"], g)
     t3 = time.time()
     n = o.shape[0] * o.shape[1]
-    return {"value": n / (t3 - t1), "unit": "rays/s", "cores": ncores, "kind": "port", "seconds": t3 - t1,
-            "sample": f"{o.shape[0]}x{o.shape[1]} = {n} rays, forward+backward, OpenMP over rays "
-                      f"(fwd {t2 - t1:.2f}s, bwd {t3 - t2:.2f}s; CPU BVH build {t1 - t0:.2f}s excluded)",
+    phys, logical = _cpu_counts()
+    return {"value": n / (t3 - t1), "unit": "rays/s", "cores": phys, "threads": ncores, "logical_cpus": logical, "kind": "port", "seconds": t3 - t1,
+            "value_with_build": n / (t3 - t0), "build_seconds": t1 - t0,
+            "sample": f"{o.shape[0]}x{o.shape[1]} = {n} rays, forward+backward, OpenMP over rays on {ncores} threads "
+                      f"({phys} physical cores; fwd {t2 - t1:.2f}s, bwd {t3 - t2:.2f}s; the oracle's single-threaded CPU BVH build, {t1 - t0:.2f}s, "
+                      f"is not in `value` -- `value_with_build` includes it, as the GPU step includes its LBVH build)",
             "cpu_model": _cpu_model()}
+
+
+def _cpu_counts():
+    """(physical cores, logical CPUs) of the host."""
+    logical = os.cpu_count() or 1
+    try:
+        cores = set(); phys_id = core_id = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"): phys_id = line.split(":")[1].strip()
+                elif line.startswith("core id"): core_id = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys_id is not None and core_id is not None: cores.add((phys_id, core_id))
+                    phys_id = core_id = None
+        if cores:
+            return len(cores), logical
+    except OSError:
+        pass
+    return logical, logical
 
 
 def _cpu_model():
@@ -98,6 +120,8 @@ def main():
     ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. fwd_mode=0, bwd_mode=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
+                    "at least this long (one window, bracketed once; `steps` in the output is what ran, `steps_requested` what was asked); 0 = exactly --steps")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
@@ -164,10 +188,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # how many blocks of --steps make the timed window at least --min-seconds long (so that driver-side telemetry can see the GPU
+    # busy): one calibration block, then ONE timed window of `reps` blocks; every rank uses the same count
+    reps = 1
+    if args.min_seconds > 0 and args.steps > 0:
+        barrier(); tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier(); cal = time.perf_counter() - tc
+        reps = max(1, int(np.ceil(args.min_seconds / max(cal, 1e-6))))
+        if world > 1:
+            tr_ = torch.tensor([reps], dtype=torch.int64, device=dev); dist.all_reduce(tr_, op=dist.ReduceOp.MAX); reps = int(tr_.item())
+    steps_run = args.steps * reps
     st.enable_timing(True)
+    tr.enable_phase_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps_run):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -177,6 +214,8 @@ def main():
         elapsed = float(te.item())
     kt = st.get_timing(dev)
     st.enable_timing(False)
+    phases = tr.phase_timing()
+    tr.enable_phase_timing(False)
 
     # ---------------- one instrumented step for the traversal statistics (untimed)
     st.enable_stats(True)
@@ -187,8 +226,8 @@ def main():
 
     if rank == 0:
         n_rays = H * W
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = n_rays * args.steps / elapsed
+        ms_per_step = 1e3 * elapsed / steps_run
+        value = n_rays * steps_run / elapsed
         # ---- roofline of the dominant kernel (per launch, this rank's slab)
         a, b = tr._slab
         rays_local = H * (b - a)
@@ -206,24 +245,37 @@ def main():
         dom = "backward (k_bwd_prep + radix sort + k_bwd_reduce3)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
         dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None; valu = None
+        traffic = None; valu = None; step_traffic = None; traffic_note = None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                ent = json.load(open(tp)).get(dom, {})
-                traffic = ent.get("hbm_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
-            except Exception:
-                traffic = None
+                from lidar_rt_amd.build import source_hash
+                pj = json.load(open(tp))
+                if pj.get("_meta", {}).get("csrc_sha") == source_hash():
+                    ent = pj.get(dom, {})
+                    traffic = ent.get("hbm_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
+                    step_traffic = pj.get("whole step (all kernels, per step)", {}).get("hbm_bytes_per_launch")
+                    traffic_note = f"rocprofv3 PMC passes of profile '{pj['_meta'].get('tag')}' (profiles/pmc_traffic.json), same kernel sources (hash {source_hash()})"
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (hash mismatch): not reported"
+            except Exception as ex:
+                traffic_note = f"profiles/pmc_traffic.json unreadable: {ex}"
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
                 # supplementary (committed rocprofv3 PMC profile): the trace kernel is bound by VALU issue, not by HBM
                 "valu_issue_frac": valu,
                 "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
                 "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b},
-                "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S}
+                "traffic_source": traffic_note,
+                # whole step: the SURVEY 8(d) byte model (its backward term, 58 read-modify-write atomics per hit, is traffic the
+                # sorted-reduction design does not move), and beside it the counter-measured bytes of ALL kernels of a step
+                "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                "whole_step_frac_counters": (step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S) if (step_traffic and world == 1) else None,
+                "whole_step_traffic": step_traffic if world == 1 else None}
         res = {
             "metric": "LiDAR rays/s fwd+bwd @1M Gaussians, 2048x64 sweep; % HBM roofline",
-            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": steps_run, "steps_requested": args.steps, "warmup": args.warmup,
+            "timed_window_s": elapsed,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
@@ -232,6 +284,9 @@ def main():
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange},
             "roofline": roof,
+            # per-phase GPU time per step on rank 0 (HIP events): LBVH build / forward trace / backward; N > 1: + slab all_gather and
+            # gradient exchange (torch events around the collectives and their pack / unpack kernels)
+            "phase_ms": {"build": ms_build, "forward": ms_f, "backward": ms_b, **{k: v for k, v in phases.items()}},
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }
         if args.check_sum:

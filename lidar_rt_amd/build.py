@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblrt_hip.so")
 SOURCES = ["lrt_kernels.hip", "lrt_chamfer.hip", "lrt_preprocess.hip"]
-HEADERS = ["lrt_math.h", "lrt_build.inc", "lrt_backward.inc", "lrt_trace_legacy.inc", "lrt_collect.inc", "lrt_collect4.inc", os.path.join("..", "..", "include", "lrt.h"),
+HEADERS = ["lrt_math.h", "lrt_device_guard.h", "lrt_build.inc", "lrt_backward.inc", "lrt_trace_legacy.inc", "lrt_collect.inc", "lrt_collect4.inc", os.path.join("..", "..", "include", "lrt.h"),
            os.path.join("..", "..", "include", "lrt_chamfer.h"), os.path.join("..", "..", "include", "lrt_knn.h"),
            os.path.join("..", "..", "include", "lrt_preprocess.h")]
 ARCH = "gfx950"
@@ -32,6 +32,16 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and headers: stamps profiles that are only valid for this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include "lrt_device_guard.h"
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/lrt.h"
@@ -647,7 +648,8 @@ lrt_chamfer* lrt_chamfer_create(int device)
         snprintf(err, CH_ERRLEN, "lrt_chamfer_create: no HIP device %d (count %d)", device, n);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) { snprintf(err, CH_ERRLEN, "lrt_chamfer_create: hipSetDevice failed"); return nullptr; }
+    LrtDeviceGuard dg_(device);
+    if (!dg_.ok) { snprintf(err, CH_ERRLEN, "lrt_chamfer_create: hipSetDevice failed"); return nullptr; }
     lrt_chamfer* ch = new lrt_chamfer();
     memset(ch, 0, sizeof(*ch));
     ch->device = device; ch->mode = 2; ch->brute_max_pairs_log2 = 24;
@@ -682,7 +684,7 @@ int lrt_chamfer_forward(lrt_chamfer* ch, int B, int N, const float* xyz1, int M,
     if ((double)N + (double)M > 2.0e9) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_forward: N + M too large");
     if (B > 0 && (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2)) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_forward: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    CH_HIPCHK(hipSetDevice(ch->device));
+    LrtDeviceGuard dg_(ch->device); if (!dg_.ok) CH_HIPCHK(hipErrorInvalidDevice);
     for (int b = 0; b < B; b++) {
         int rc = ch_forward_one(ch, N, xyz1 + (size_t)b * N * 3, M, xyz2 + (size_t)b * M * 3, dist1 + (size_t)b * N,
                                 dist2 + (size_t)b * M, idx1 + (size_t)b * N, idx2 + (size_t)b * M, stream);
@@ -698,7 +700,7 @@ int lrt_knn_mean_dist2(lrt_chamfer* ch, int P, const float* points, float* mean_
     if (P == 0) return LRT_OK;
     if (!points || !mean_dist2) CH_FAIL(LRT_ERR_ARG, "lrt_knn_mean_dist2: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    CH_HIPCHK(hipSetDevice(ch->device));
+    LrtDeviceGuard dg_(ch->device); if (!dg_.ok) CH_HIPCHK(hipErrorInvalidDevice);
     int rc = ch_ensure(ch, (size_t)P + 128, 0, stream);
     if (rc != LRT_OK) return rc;
     ChParams p; int Kmax = 0, total_pts = 0;
@@ -717,7 +719,7 @@ int lrt_chamfer_backward(lrt_chamfer* ch, int B, int N, const float* xyz1, int M
     if (B > 0 && (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2))
         CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_backward: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    CH_HIPCHK(hipSetDevice(ch->device));
+    LrtDeviceGuard dg_(ch->device); if (!dg_.ok) CH_HIPCHK(hipErrorInvalidDevice);
     const int n = N + M;
     for (int b = 0; b < B; b++) {
         const float *a = xyz1 + (size_t)b * N * 3, *c = xyz2 + (size_t)b * M * 3;

@@ -87,6 +87,9 @@ struct lrt_state {
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float2* hit_wa; int defer_colour; int fast_valid;
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 2 = lane per hit + LDS-transposed column sums (default), 1 = lane per hit + DPP segmented scan, 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
+    // stream-ordered backward: when the forward's status words have not reached the host yet, the backward is enqueued with sizes
+    // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
+    int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin; hipStream_t last_stream;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
@@ -130,6 +133,9 @@ struct TraceParams {
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
     const unsigned long long* sorted_keys; unsigned n_hits;
+    // device-side decisions of the stream-ordered backward: guard = 1 -> run only if the hit record is complete and holds at most
+    // n_spec hits, 2 -> run only if NOT (the re-tracing fallback), 0 -> unconditional; n_hits_dev = the forward's hit counter
+    const unsigned* n_hits_dev; unsigned n_spec; int guard;
     float4* hit_pk;        // per hit (t, dL/dalpha, +-w, -) written by k_bwd_replay<false>, one 16-B gather in k_bwd_reduce
     float4* ray_pk;        // per ray 4 x float4: (o, dL3) (d, -) (dL0..2, -) (dL5..7, -)
     // collect & resolve forward
@@ -309,7 +315,9 @@ __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ acc
                                                   unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (i < 16) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;     // [10] err_flag: 8 = the culled build lost primitives
+    // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
+    // [12] STICKY error bits (only the host clears them), [16..23] tile queues of a re-tracing backward
+    if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
         for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -377,7 +385,7 @@ struct ScopedTimer {
     lrt_state* st; hipStream_t stream; lrt_state::TimerSlot* slot = nullptr;
     ScopedTimer(lrt_state* s, int kind, hipStream_t str) : st(s), stream(str)
     {
-        if (!st->timing_enabled) return;
+        if (!st->timing_enabled || kind < 0) return;
         if (st->timers_used == st->timers->size()) {
             lrt_state::TimerSlot t; t.kind = kind;
             if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
@@ -411,15 +419,18 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 2; st->slab0 = 24.0f;          // tiles 4 wide: 4x4 rays (CR_SLOTS 4) or 2x4 rays (CR_SLOTS 8)
-    if (hipMalloc(&st->ctrl, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 16 * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void**)&st->hit_ovf_host, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hit-record setup failed");
         delete st->timers; delete st;
         return nullptr;
     }
     st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9;
     st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
-    st->hit_ovf_host[0] = 0; st->hit_ovf_host[1] = 0; st->hit_ovf_host[2] = 0; st->hit_ovf_host[3] = 0;
+    for (int i = 0; i < 8; i++) st->hit_ovf_host[i] = 0;
+    st->spec_bwd = 1; st->spec_margin = 65536;
     const unsigned bounds_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     if (hipMalloc(&st->bounds, 12 * sizeof(unsigned)) != hipSuccess || hipMemcpy(st->bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
@@ -451,7 +462,7 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
 {
     if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
     const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
-        {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}};
+        {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
     LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: unknown option '%s'", name);
 }
@@ -475,6 +486,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "spec_margin")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: spec_margin must be >= 0"); st->spec_margin = value; return LRT_OK; }   // hits added to the speculated size (tests set 0)
+    if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
     if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
     if (!strcmp(name, "cull_guess")) { st->cull_guess = value; return LRT_OK; }   // test hook: speculative size of the NEXT culled build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
@@ -522,7 +535,7 @@ static int grad_rows(const char* fn, bool gather, int device, int P, int M, int 
     if (P < 0 || M < 0 || n < 0 || n > P) LRT_FAIL(LRT_ERR_ARG, "%s: bad sizes P=%d M=%d n=%d", fn, P, M, n);
     if (n == 0) return LRT_OK;
     if (!idx || !rows || !d_means || !d_scales || !d_rots || !d_opac || !accum || (M > 0 && !d_shs)) LRT_FAIL(LRT_ERR_ARG, "%s: null pointer", fn);
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "%s: cannot select HIP device %d", fn, device);
     GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rots; g.w[2] = 4; g.f[3] = d_opac; g.w[3] = 1;
     g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
     const int width = 11 + 3 * M;
@@ -549,19 +562,43 @@ int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, co
                      d_opacities, d_shs, accum, stream);
 }
 
+// The status block of the most recent COMPLETED forward is on the host (st->hit_ovf_host, written by k_fwd_fin): take what the
+// next calls need from it -- the composited-hit count as the size estimate of a speculatively enqueued backward, capacity growth
+// after an overflow of the hit record / key list -- and return the error bits (sticky: every forward since the last report).
+static int absorb_status(lrt_state* st)
+{
+    st->fwd_pending = 0;
+    if (st->est_pending) {
+        st->est_pending = 0;
+        const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
+        st->est_hits = n_hits; st->est_hw = st->pend_hw; st->est_valid = 1;
+        // a ray composited more hits than the record holds (that frame's backward re-traces): the following frames record with twice
+        // the capacity; more hits than the dense key list holds: a longer key list
+        if (st->hit_ovf_host[0] != 0 && st->hit_cap_auto && st->hit_cap < 4096 && st->pend_hw * (size_t)st->hit_cap * 2 < (1ull << 32)) st->hit_cap *= 2;
+        if (st->bwd_mode == 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;
+    }
+    return st->hit_ovf_host[4] | st->hit_ovf_host[2];
+}
+
+static int report_overflow(lrt_state* st, const char* fn, int code, hipStream_t stream)
+{
+    (void)hipMemsetAsync(st->ctrl + 12, 0, sizeof(unsigned), stream);      // the sticky bits are reported once
+    st->hit_ovf_host[4] = 0; st->hit_ovf_host[2] = 0;
+    LRT_FAIL(LRT_ERR_STATE, "%s: a forward trace reported an internal overflow and its output is incomplete [code %d: 1 = more than 256 "
+             "candidate quads within 0.1 mm along one ray, 2 = BVH queue/stack, 4 = colour overflow list (raise the hit_cap option), 8 = the "
+             "speculatively sized ray-culled build lost primitives (the next build reads its size back; option spec_cull=0 disables)]; "
+             "for 1/2 use option fwd_mode=0", fn, code);
+}
+
 int lrt_check_forward(lrt_state* st, int wait)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_check_forward: null state");
     if (!st->fwd_pending) return LRT_OK;
+    DeviceGuard dg(st->device);
     if (wait) HIPCHK(hipEventSynchronize(st->hit_ev));
-    else if (hipEventQuery(st->hit_ev) != hipSuccess) return LRT_OK;            // still running: ask again later
-    st->fwd_pending = 0;
-    const int code = st->hit_ovf_host[2];
-    if (code != 0)
-        LRT_FAIL(LRT_ERR_STATE, "the last forward trace reported an internal overflow and its output is incomplete [code %d: 1 = more than 256 "
-                 "candidate quads within 0.1 mm along one ray, 2 = BVH queue/stack, 4 = colour overflow list (raise the hit_cap option), 8 = the "
-                 "speculatively sized ray-culled build lost primitives (the next build reads its size back; option spec_cull=0 disables)]; "
-                 "for 1/2 use option fwd_mode=0", code);
+    else if (hipEventQuery(st->hit_ev) != hipSuccess) return LRT_OK;            // still running: ask again later (errors are sticky)
+    const int code = absorb_status(st);
+    if (code != 0) return report_overflow(st, "lrt_forward", code, st->last_stream);
     return LRT_OK;
 }
 
@@ -779,10 +816,11 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     tp.stats = st->stats_enabled ? st->stats : nullptr;
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
-    HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
+    if (bwd && st->bwdq_fresh) { tp.tile_counter = st->ctrl + 16; st->bwdq_fresh = 0; }       // zeroed by the forward's prologue, used once
+    else HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
     int blocks = (tp.n_tiles + 3) / 4;
     if (blocks > 256 * 3) blocks = 256 * 3;                       // persistent: <= 3 blocks (12 waves) per CU
-    ScopedTimer tm(st, bwd ? 2 : 1, stream);
+    ScopedTimer tm(st, tp.guard == 2 ? -1 : (bwd ? 2 : 1), stream);      // the guarded fallback lies inside the caller's timed region
     if (bwd) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
     else     hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
     HIPCHK(hipGetLastError());
@@ -928,21 +966,23 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             if (dfr) {
                 const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
-                hipLaunchKernelGGL(k_fwd_colour_ovf, dim3(256), dim3(256), 0, stream, tp);
-            }
+            } else { tp.ovf_list = nullptr; }
         }
         HIPCHK(hipGetLastError());
     } else {
         rc = launch_trace(st, tp, false, stream);
         if (rc) return rc;
+        tp.ovf_list = nullptr;
     }
-    // [hit_ovf, hit_count, err_flag, ovf_count] in one 16-byte copy
-    HIPCHK(hipMemcpyAsync(st->hit_ovf_host, st->ctrl + 8, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // epilogue: colours of the hits beyond the record (deferred colour), status words -> host-mapped block, sticky error bits
+    hipLaunchKernelGGL(k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->hit_ev, stream));
-    st->fwd_pending = 1;
+    st->fwd_pending = 1; st->last_stream = stream; st->bwdq_fresh = 1;
     if (record) {
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
         st->fast_valid = (st->hits_valid && defer) ? 1 : 0;          // alpha and colour of every recorded hit are on the device
+        if (st->hits_valid) { st->est_pending = 1; st->pend_hw = HW; }
     }
     return LRT_OK;
 }
@@ -979,17 +1019,32 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.out9_in = out9; tp.dL_dout = dL_dout9;
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
-        HIPCHK(hipEventSynchronize(st->hit_ev));          // the overflow flag copy; long done by the time backward runs
-        if (st->hit_ovf_host[2] != 0) LRT_FAIL(LRT_ERR_STATE, "lrt_backward: the forward trace reported an internal overflow [code %d: 1 = list (more than 256 candidate quads within 0.1 mm along one ray), 2 = BVH stack, 4 = colour overflow list (> 2^20 composited hits beyond hit_cap; raise the hit_cap option), 8 = the speculatively sized ray-culled build lost primitives (the next build reads its size back)]; for 1/2 use option fwd_mode=0", st->hit_ovf_host[2]);
-        const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
-        if (st->hit_ovf_host[0] == 0) {
+        // The sort and the reduction are sized by the number of composited hits, which the forward counted on the device.  If its
+        // status block has already reached the host the exact number is used.  Otherwise the host does NOT wait (the launch queue
+        // would drain): the work is enqueued for a SPECULATED size -- the count of the last completed forward of this image size
+        // x 1.125 + 64 k -- and the kernels decide on the device: hit record complete and within the size -> sorted reduction, else
+        // the re-tracing fallback (enqueued behind it, returns at once when not needed).  Only the first backward of an image size
+        // waits for the forward.
+        bool ready = hipEventQuery(st->hit_ev) == hipSuccess;
+        const bool can_spec = st->spec_bwd && st->bwd_mode == 2 && st->est_valid && st->est_hw == (size_t)H * W && st->hit_keys;
+        if (!ready && !can_spec) { HIPCHK(hipEventSynchronize(st->hit_ev)); ready = true; }
+        unsigned n_hits = 0; bool record_ok = true, spec = false;
+        st->last_bwd_spec = ready ? 0 : 1;
+        if (ready) {
+            const int code = absorb_status(st);
+            if (code != 0) return report_overflow(st, "lrt_backward", code, stream);
+            n_hits = (unsigned)st->hit_ovf_host[1]; record_ok = st->hit_ovf_host[0] == 0;
+        } else {
+            unsigned long long g = (unsigned long long)st->est_hits + st->est_hits / 8 + (unsigned long long)st->spec_margin;
+            n_hits = (unsigned)(g < st->key_cap ? g : st->key_cap); spec = true;
+        }
+        if (record_ok) {
             const int TW = 1 << st->tile_w_log2, TH = 64 / TW;
             tp.tw_log2 = st->tile_w_log2; tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH;
             tp.n_tiles = tp.tiles_x * tp.tiles_y; tp.nsh = (deg + 1) * (deg + 1);
             tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
-            tp.hw = H * W;
+            tp.hw = H * W; tp.hit_ovf = st->hit_ovf;
             const bool sorted = (st->bwd_mode == 2) && st->hit_keys && n_hits <= st->key_cap;
-            if (st->bwd_mode == 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;   // this frame: atomics; next: a longer key list
             if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
                 hipLaunchKernelGGL(k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
@@ -1001,6 +1056,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                   HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
                 int id_bits = 1; while ((1ull << id_bits) < (unsigned long long)H * W * (unsigned long long)tp.hit_cap) id_bits++;
                 tp.hit_off = st->hit_off; tp.hit_keys = st->hit_keys; tp.key_cap = st->key_cap; tp.id_bits = id_bits;
+                if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = n_hits; }
                 {
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
@@ -1015,22 +1071,26 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     // is the same as a full-key sort would give (3 instead of 6 radix passes)
                     HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
-                    if (st->reduce_mode == 0) {
+                    if (st->reduce_mode == 0 && !spec) {
                         const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
                         hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
-                    } else if (st->reduce_mode == 2) {
+                    } else if (st->reduce_mode == 2 || spec) {
                         hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                     } else {
                         hipLaunchKernelGGL(k_bwd_reduce2, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                     }
                 }
+                if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise)
+                    tp.guard = 2;
+                    HIPCHK(hipGetLastError());
+                    return launch_trace(st, tp, true, stream);
+                }
             }
             HIPCHK(hipGetLastError());
             return LRT_OK;
         }
-        // a ray composited more hits than the record holds: this frame is re-traced (an order of magnitude slower), the
-        // following ones record with twice the capacity
-        if (st->hit_cap_auto && st->hit_cap < 4096 && (size_t)H * W * (size_t)st->hit_cap * 2 < (1ull << 32)) st->hit_cap *= 2;
+        // a ray composited more hits than the record holds: this frame is re-traced (an order of magnitude slower); absorb_status
+        // has doubled the capacity for the following ones
     }
     return launch_trace(st, tp, true, stream);   // no (complete) record: re-trace like the reference
 }

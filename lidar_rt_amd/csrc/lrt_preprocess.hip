@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
+#include "lrt_device_guard.h"
 
 #include "../../include/lrt.h"
 #include "../../include/lrt_preprocess.h"
@@ -137,7 +138,7 @@ int lrt_preprocess_forward(int device, int P, int A, const int32_t* seg_start, c
     if (P == 0) return LRT_OK;
     if (!xyz || !log_scales || !rot_raw || !opacity_logit || !means || !scales || !rotations || !opacities)
         PP_FAIL(LRT_ERR_ARG, "lrt_preprocess_forward: null pointer");
-    PP_HIPCHK(hipSetDevice(device));
+    LrtDeviceGuard dg_(device); if (!dg_.ok) PP_HIPCHK(hipErrorInvalidDevice);
     hipLaunchKernelGGL(k_pp_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, A, seg_start, poses, xyz,
                        log_scales, rot_raw, opacity_logit, means, scales, rotations, opacities);
     PP_HIPCHK(hipGetLastError());
@@ -155,7 +156,7 @@ int lrt_preprocess_backward(int device, int P, int A, const int32_t* seg_start, 
     if (!rot_raw || !scales || !opacities || !d_means || !d_scales || !d_rotations || !d_opacities || !d_xyz || !d_log_scales ||
         !d_rot_raw || !d_opacity_logit)
         PP_FAIL(LRT_ERR_ARG, "lrt_preprocess_backward: null pointer");
-    PP_HIPCHK(hipSetDevice(device));
+    LrtDeviceGuard dg_(device); if (!dg_.ok) PP_HIPCHK(hipErrorInvalidDevice);
     hipLaunchKernelGGL(k_pp_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, A, seg_start, poses, rot_raw,
                        scales, opacities, d_means, d_scales, d_rotations, d_opacities, d_xyz, d_log_scales, d_rot_raw,
                        d_opacity_logit);

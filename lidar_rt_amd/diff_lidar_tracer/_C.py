@@ -37,6 +37,7 @@ class OptiXStateWrapper:
         self._handles = {}          # device index -> lrt_state*
         self._dirty = {}            # device index -> bool
         self._built_P = {}
+        self._built_mod = {}        # device index -> scale modifier of the current structure
         self.refit_interval = 0     # > 0: that many lrt_refit calls between full builds of an unchanged number of Gaussians
         self._since_full = {}; self._full_P = {}
         self.stats_enabled = False
@@ -64,7 +65,6 @@ class OptiXStateWrapper:
     def mark_dirty(self):
         for k in self._dirty:
             self._dirty[k] = True
-        self._any_dirty = True
 
     def set_option(self, name: str, value: int):
         self.options[name] = int(value)
@@ -82,8 +82,12 @@ class OptiXStateWrapper:
 
     def check(self, device=None, wait: bool = True):
         """Raise if the most recent forward on `device` reported an internal overflow (waits for it when `wait`)."""
+        want = None
+        if device is not None:
+            dv = torch.device(device)
+            want = dv.index if dv.index is not None else torch.cuda.current_device()
         for idx, h in self._handles.items():
-            if device is None or idx == (torch.device(device).index or 0):
+            if want is None or idx == want:
                 _capi.check(self._lib.lrt_check_forward(h, 1 if wait else 0), "lrt_forward")
 
     def enable_stats(self, enable: bool = True):
@@ -199,6 +203,7 @@ def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, o
                                                       _stream_ptr()), "lrt_build_for_rays")
     state._dirty[idx] = False
     state._built_P[idx] = P
+    state._built_mod[idx] = float(scale_modifier)
     # keep the inputs alive until the stream has consumed them (stream-ordered, no sync)
     state._keep = (m, s, r, o)
 
@@ -232,8 +237,8 @@ def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertic
     M = shs.size(1) if shs.numel() > 0 else 0
     dev = means3D.device
     idx, h = state.handle(dev)
-    if state._dirty.get(idx, True) or state._built_P.get(idx, -1) != P:
-        build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier)
+    if state._dirty.get(idx, True) or state._built_P.get(idx, -1) != P or state._built_mod.get(idx) != float(scale_modifier):
+        build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier)   # also when the scale modifier changed
     ro, rd = ray_o.detach().contiguous(), ray_d.detach().contiguous()      # ray_o is an expanded view upstream
     bg = background.detach().contiguous()
     sh = shs.detach().contiguous()

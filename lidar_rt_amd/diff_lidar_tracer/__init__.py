@@ -36,14 +36,15 @@ class _Tracer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state, training, ray_o, ray_d, vertices, means3D, grads3D, shs, colors_precomp, opacities,
-                scales, rotations, cov3Ds_precomp, tracer_settings):
+                scales, rotations, cov3Ds_precomp, tracer_settings, check_now=False):
         ts = tracer_settings
         out_f32, out_i32, accum = _C.trace_surfels(
             state, training, ray_o, ray_d, vertices, ts.bg, means3D, shs, ts.sh_degree, colors_precomp, opacities,
             scales, ts.scale_modifier, rotations, cov3Ds_precomp, ts.viewmatrix, ts.projmatrix, ts.campos,
             ts.prefiltered, ts.debug)
-        if not training or not torch.is_grad_enabled():
-            # no backward will follow to look at the overflow flag: wait for the trace and fail loudly now
+        if check_now:
+            # decided by Tracer.forward (grad mode is always off in here): no backward will follow to look at the overflow
+            # status, so wait for the trace and fail loudly now
             state.check(means3D.device, wait=True)
         ctx.tracer_settings = ts
         ctx.state = state
@@ -65,7 +66,7 @@ class _Tracer(torch.autograd.Function):
         g_opac = g_opac.reshape(opacities.shape)
         g_colors = g_colors if colors_precomp.numel() > 0 else None
         g_cov = g_cov if cov3Ds_precomp.numel() > 0 else None
-        return (None, None, None, None, None, g_means, g_g3, g_shs, g_colors, g_opac, g_scales, g_rot, g_cov, None)
+        return (None, None, None, None, None, g_means, g_g3, g_shs, g_colors, g_opac, g_scales, g_rot, g_cov, None, None)
 
 
 class Tracer(nn.Module):
@@ -75,6 +76,7 @@ class Tracer(nn.Module):
         # lib/gaussian_renderer/__init__.py:11); ours is a cheap host object, device state is created lazily
         self.optix_context = _C.OptiXStateWrapper("")
         self.vertices = None
+        self.deferred_checks = False     # True: forwards without a backward do not wait for the trace; call check() once per batch
 
     # ---- reference surface -------------------------------------------------------------------
     def build_acceleration_structure(self, vertices: torch.Tensor, triangles: torch.Tensor, rebuild: bool = 1):
@@ -98,8 +100,20 @@ class Tracer(nn.Module):
         if rotations is None: rotations = empty
         if cov3Ds_precomp is None: cov3Ds_precomp = empty
         vertices = self.vertices if self.vertices is not None else empty
-        return _Tracer.apply(self.optix_context, self.training, ray_o, ray_d, vertices, means3D, grads3D, shs,
-                             colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tracer_settings)
+        # The trace is stream-ordered and reports an internal overflow through a status block that the NEXT call into the library
+        # reads.  With a backward to follow (training mode, grad mode on, some input requires a gradient) nothing waits here; without
+        # one the host waits for the trace and raises now -- unless `deferred_checks` is set (evaluation loops: render many frames,
+        # then call `check()` once).
+        will_backward = self.training and torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, grads3D, shs, opacities, scales, rotations))
+        check_now = not will_backward and not self.deferred_checks
+        return _Tracer.apply(self.optix_context, self.training and will_backward, ray_o, ray_d, vertices, means3D, grads3D, shs,
+                             colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tracer_settings, check_now)
+
+    def check(self, device=None):
+        """Wait for the most recent forward on `device` and raise if any forward since the last check reported an internal
+        overflow (the status bits are sticky).  For loops that run with ``deferred_checks = True``."""
+        self.optix_context.check(device, wait=True)
 
     # ---- additions ---------------------------------------------------------------------------
     def build_from_gaussians(self, means3D, scales, rotations, opacities, scale_modifier: float = 1.0):

@@ -100,6 +100,44 @@ class ShardedTracer:
         self.cull_build = self.world >= 8
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
+        self._phase_on = False
+        self._phase_ev = []            # (name, start event, end event) of the collectives' regions, read back by phase_timing()
+
+    # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
+    def enable_phase_timing(self, on: bool = True):
+        self._phase_on = bool(on); self._phase_ev = []
+
+    class _Region:
+        def __init__(self, owner, name, device):
+            self.o, self.name, self.cuda = owner, name, (device.type == "cuda" and owner._phase_on)
+        def __enter__(self):
+            if self.cuda:
+                self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True); self.a.record()
+        def __exit__(self, *exc):
+            if self.cuda:
+                self.b.record(); self.o._phase_ev.append((self.name, self.a, self.b))
+
+    def phase_timing(self) -> Dict[str, float]:
+        """Mean ms per call of every timed region since enable_phase_timing (synchronises)."""
+        if not self._phase_ev:
+            return {}
+        torch.cuda.synchronize()
+        acc: Dict[str, list] = {}
+        for name, a, b in self._phase_ev:
+            acc.setdefault(name, []).append(a.elapsed_time(b))
+        self._phase_ev = []
+        return {k: float(sum(v) / len(v)) for k, v in acc.items()}
+
+    @staticmethod
+    def _backend_takes(fn, name: str) -> bool:
+        """Capability of an injected backend, from its signature (a TypeError raised INSIDE the backend must not be mistaken for
+        a missing keyword)."""
+        import inspect
+        try:
+            ps = inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return False
+        return name in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
 
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
         H, W = ray_o.shape[:2]
@@ -110,9 +148,9 @@ class ShardedTracer:
         # cone from 3 ranks on (slabs narrower than ~120 degrees); such a structure must be rebuilt for every ray set
         cull = (self._ro, self._rd) if (self.world >= 3 and self.cull_build) else None
         if rebuild or cull is not None:
-            try:
+            if self._backend_takes(self.backend.build, "cull_rays"):
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)
-            except TypeError:                                                     # backend without culling (test stand-ins)
+            else:                                                                 # backend without culling (test stand-ins)
                 self.backend.build(means, scales, rotations, opacities, mod)
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
@@ -121,14 +159,16 @@ class ShardedTracer:
             return out_loc, accum_loc
         # all_gather needs equal shapes: pad slabs to the widest one
         wmax = max(column_slab(W, r, self.world)[1] - column_slab(W, r, self.world)[0] for r in range(self.world))
-        pad = torch.zeros((H, wmax, 9), dtype=out_loc.dtype, device=out_loc.device)
-        pad[:, :b - a] = out_loc
-        parts = self._all_gather_rows(pad)               # one flat receive buffer with RCCL
-        cols = []
-        for r in range(self.world):
-            ra, rb = column_slab(W, r, self.world)
-            cols.append(parts[r][:, :rb - ra])
-        return torch.cat(cols, dim=1), accum_loc        # accum is completed by backward()'s fused reduction
+        with self._Region(self, "slab_all_gather", out_loc.device):
+            pad = torch.zeros((H, wmax, 9), dtype=out_loc.dtype, device=out_loc.device)
+            pad[:, :b - a] = out_loc
+            parts = self._all_gather_rows(pad)               # one flat receive buffer with RCCL
+            cols = []
+            for r in range(self.world):
+                ra, rb = column_slab(W, r, self.world)
+                cols.append(parts[r][:, :rb - ra])
+            full = torch.cat(cols, dim=1)
+        return full, accum_loc                          # accum is completed by backward()'s fused reduction
 
     def backward(self, means, scales, rotations, opacities, shs, deg, bg, dL_full, mod=1.0,
                  reduce: bool = True) -> Dict[str, torch.Tensor]:
@@ -139,10 +179,10 @@ class ShardedTracer:
         if lay is None or lay.P != P or lay.M != M or lay.flat.device != means.device:
             lay = self._layout = GradLayout(P, M, means.device)           # reused across steps: no per-step 240 MB allocation
         direct = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
-        try:
+        if self._backend_takes(self.backend.backward, "grads_out"):
             self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
                                   self._out_loc, dL, mod, grads_out=direct)      # kernels write straight into the flat buffer
-        except TypeError:                                                         # backend without grads_out (test stand-ins)
+        else:                                                                     # backend without grads_out (test stand-ins)
             g = self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
                                       self._out_loc, dL, mod)
             for k in direct:
@@ -150,9 +190,10 @@ class ShardedTracer:
         lay.views["accum"].copy_(self._accum_loc)
         self.last_exchange = None
         if reduce and self.world > 1:
-            if self.exchange == "dense" or not self._exchange_sparse(lay):
-                dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.last_exchange = "dense"
+            with self._Region(self, "gradient_exchange", lay.flat.device):
+                if self.exchange == "dense" or not self._exchange_sparse(lay):
+                    dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
+                    self.last_exchange = "dense"
         return lay.views
 
     @staticmethod

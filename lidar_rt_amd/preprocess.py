@@ -47,9 +47,10 @@ class _FusedActivations(torch.autograd.Function):
         p = _capi.ptr
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        _capi.check(_capi.load().lrt_preprocess_forward(idx, P, A, p(seg_start), p(poses), p(xyz), p(log_scales), p(rot_raw),
-                                                        p(opacity_logit), p(means), p(scales), p(rots), p(opac), stream),
-                    "lrt_preprocess_forward")
+        with torch.cuda.device(idx):
+            _capi.check(_capi.load().lrt_preprocess_forward(idx, P, A, p(seg_start), p(poses), p(xyz), p(log_scales), p(rot_raw),
+                                                            p(opacity_logit), p(means), p(scales), p(rots), p(opac), stream),
+                        "lrt_preprocess_forward")
         ctx.save_for_backward(rot_raw, scales, opac, seg_start, poses)
         return means, scales, rots, opac
 
@@ -66,9 +67,10 @@ class _FusedActivations(torch.autograd.Function):
         p = _capi.ptr
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        _capi.check(_capi.load().lrt_preprocess_backward(idx, P, A, p(seg_start), p(poses), p(rot_raw), p(scales), p(opac),
-                                                         p(d_means), p(d_scales), p(d_rots), p(d_opac), p(d_xyz), p(d_ls),
-                                                         p(d_rot), p(d_lo), stream), "lrt_preprocess_backward")
+        with torch.cuda.device(idx):
+            _capi.check(_capi.load().lrt_preprocess_backward(idx, P, A, p(seg_start), p(poses), p(rot_raw), p(scales), p(opac),
+                                                             p(d_means), p(d_scales), p(d_rots), p(d_opac), p(d_xyz), p(d_ls),
+                                                             p(d_rot), p(d_lo), stream), "lrt_preprocess_backward")
         return d_xyz, d_ls, d_rot, d_lo, None, None
 
 

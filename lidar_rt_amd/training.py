@@ -74,7 +74,7 @@ class GaussianAsset:
     def from_points(cls, points: torch.Tensor, intensity: torch.Tensor, normals: Optional[torch.Tensor] = None, **kw):
         """Initialisation from a point cloud (gaussian_model.py:155-184): scales from the mean squared distance to the
         3 nearest neighbours (``distCUDA2``), opacity 0.1, DC feature = RGB2SH(colour), flat quaternions."""
-        from simple_knn._C import distCUDA2
+        from .simple_knn._C import distCUDA2          # the package's own operator, not whatever top-level `simple_knn` is installed
         self = cls(**kw)
         pts = points.float().contiguous()
         P, dev = pts.shape[0], pts.device

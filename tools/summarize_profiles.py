@@ -93,6 +93,21 @@ if fw:
 bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
 if bw:
     traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce3)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
+# whole step from the counters: all dispatches of the PMC runs, per step (= per k_fwd_cr4 dispatch)
+tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}; steps_pmc = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+for k, c in pmc.items():
+    for n in tot:
+        if n in c:
+            tot[n] += c[n][0]
+            if k.startswith("k_fwd_cr4"): steps_pmc[n] += c[n][1]
+if steps_pmc["FETCH_SIZE"] and steps_pmc["WRITE_SIZE"]:
+    traffic["whole step (all kernels, per step)"] = {
+        "hbm_bytes_per_launch": (2 * tot["FETCH_SIZE"] / steps_pmc["FETCH_SIZE"] + tot["WRITE_SIZE"] / steps_pmc["WRITE_SIZE"]) * 1024,
+        "raw_bytes_per_launch": (tot["FETCH_SIZE"] / steps_pmc["FETCH_SIZE"] + tot["WRITE_SIZE"] / steps_pmc["WRITE_SIZE"]) * 1024}
+sys.path.insert(0, REPO)
+from lidar_rt_amd.build import source_hash
+traffic["_meta"] = {"tag": tag, "csrc_sha": source_hash(), "note": "valid only for the kernel sources with this hash (lidar_rt_amd.build.source_hash); "
+                    "bench.py reports traffic = null when the sources have changed since"}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
