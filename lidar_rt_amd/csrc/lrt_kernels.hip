@@ -484,7 +484,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     }
     if (!strcmp(name, "hit_cap_auto")) { st->hit_cap_auto = value ? 1 : 0; return LRT_OK; }   // 1 (default): the record capacity doubles after an overflow
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
-    if (!strcmp(name, "fwd_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0, 1 or 2"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "fwd_mode")) { if (value != 0 && value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 (K-buffer packets) or 2 (collect & resolve, default); mode 1 was retired"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
     if (!strcmp(name, "spec_margin")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: spec_margin must be >= 0"); st->spec_margin = value; return LRT_OK; }   // hits added to the speculated size (tests set 0)
     if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
@@ -503,7 +503,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
     if (!strcmp(name, "defer_colour")) { st->defer_colour = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
-    if (!strcmp(name, "reduce_mode")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: reduce_mode must be 0, 1 or 2"); st->reduce_mode = value; return LRT_OK; }
+    if (!strcmp(name, "reduce_mode")) { if (value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: reduce_mode 0 and 1 were retired (k_bwd_reduce3 = mode 2 is the reduction)"); return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
         if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
@@ -864,7 +864,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     st->hits_valid = 0; st->fast_valid = 0;
     st->fwd_serial++;
     const size_t HW = (size_t)H * W;
-    const bool defer = (st->fwd_mode == 1 || st->fwd_mode == 2) && st->defer_colour;                 // the colour pass reads the hit record
+    const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc || st->key_avg > st->key_avg_alloc) {
@@ -900,10 +900,10 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         if (defer && !st->ovf_list) HIPCHK(hipMalloc(&st->ovf_list, (size_t)st->ovf_cap * sizeof(float4)));
         tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
     }
-    if (st->fwd_mode == 1 || st->fwd_mode == 2) {
-        const bool wg4 = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26);   // one workgroup of 4 waves per 16-ray tile (k_fwd_cr4,
-                                                                     // 32-bit byte offsets into the leaf records); k_fwd_cr beyond
-        const int tile_rays = wg4 ? C4_RAYS : CR_RAYS;
+    // k_fwd_cr4 addresses the leaf records with 32-bit byte offsets: beyond 2^26 primitives the K-buffer packet kernel takes over
+    if (st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26)) {
+        const bool wg4 = true;                                      // one workgroup of 4 (or 8) waves per 16-ray tile: k_fwd_cr4
+        const int tile_rays = C4_RAYS;
         const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
         tp.tw_log2 = st->tile16_w_log2;
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
@@ -923,7 +923,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 HIPCHK(hipStreamSynchronize(stream));
                 (void)hipFree(st->cr_lists); st->cr_lists = nullptr; st->cr_blocks_cap = 0;
                 const int cap = blocks < 256 ? 256 : 256 * 16;
-                const size_t words = CR_LIST_WORDS > C4_LIST_WORDS ? CR_LIST_WORDS : C4_LIST_WORDS;
+                const size_t words = C4_LIST_WORDS;
                 HIPCHK(hipMalloc(&st->cr_lists, (size_t)cap * words * sizeof(float)));
                 st->cr_blocks_cap = cap;
             }
@@ -947,7 +947,6 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 int n0 = -1, n1 = -1, n2 = -1;
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<true, 4>, 256, 0);
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true, 8>, 512, 0);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_fwd_cr<true>, 64, 0);
                 fprintf(stderr, "[lrt] occupancy blocks/CU: k_fwd_cr4<true,4> %d, k_fwd_cr4<true,8> %d, k_fwd_cr<true> %d; launching %d blocks of %d waves\n", n0, n1, n2, blocks, nw);
             }
             ScopedTimer tm(st, 1, stream);
@@ -956,12 +955,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             if (wg4 && nw == 8) {
                 if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
                 else hipLaunchKernelGGL((k_fwd_cr4<false, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
-            } else if (wg4) {
+            } else {
                 if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
                 else hipLaunchKernelGGL((k_fwd_cr4<false, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
-            } else {
-                if (dfr) hipLaunchKernelGGL(k_fwd_cr<true>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
-                else hipLaunchKernelGGL(k_fwd_cr<false>, dim3(blocks), dim3(64), 0, stream, tp, rec_, naos_);
             }
             if (dfr) {
                 const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
@@ -1071,14 +1067,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     // is the same as a full-key sort would give (3 instead of 6 radix passes)
                     HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
                     tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
-                    if (st->reduce_mode == 0 && !spec) {
-                        const unsigned nthreads = (n_hits + LRT_RED_CH - 1) / LRT_RED_CH;
-                        hipLaunchKernelGGL(k_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, stream, tp);
-                    } else if (st->reduce_mode == 2 || spec) {
-                        hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
-                    } else {
-                        hipLaunchKernelGGL(k_bwd_reduce2, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
-                    }
+                    hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                 }
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise)
                     tp.guard = 2;

@@ -36,3 +36,15 @@ for name, k in (("clk_us", None), ("slabs", 1), ("nodes", 2), ("prim_rounds", 3)
     v = clk if k is None else buf[..., k]
     print(name, "by tile row:", np.round(v.mean(1), 1).tolist())
     print(name, "max by tile row:", np.round(v.max(1), 1).tolist())
+
+if os.environ.get("C4_PROF"):
+    raw = np.empty(16384 * 64, np.float32)
+    be.state._lib.lrt_debug_read(h, 4, raw.ctypes.data_as(C.c_void_p), raw.nbytes, None)
+    pr = raw[8 * NT: 8 * NT + 16 * NT].reshape(NT, 16)[:, :10]
+    names = ["first select+commit", "select_issue(next)", "process leaves", "process nodes", "round barrier", "push counters + late select", "commit (vmcnt wait + LDS stores)",
+             "phase A tail (waitcnt, barrier, overflow test)", "slab prologue (barriers, flags)", "phase B"]
+    tot = pr.sum()
+    print("wave-0 cycles per tile by segment (mean; share):")
+    for k, n in enumerate(names):
+        print("  %-48s %9.0f  %5.1f %%" % (n, pr[:, k].mean(), 100 * pr[:, k].sum() / tot))
+    print("  total cycles per tile %.0f (%.1f us at 2.4 GHz)" % (pr.sum(1).mean(), pr.sum(1).mean() / 2400))
