@@ -30,7 +30,9 @@
 #include "../../include/lrt.h"
 #include "lrt_math.h"
 
+#ifndef LRT_LEAF
 #define LRT_LEAF 8            // primitives per leaf (tested exhaustively by the packet)
+#endif
 #define LRT_NODE_FLOATS 64    // 48 box floats (SoA lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]) + header, 256 B
 #define LRT_MAX_LEVELS 12
 // An EMPTY child slot is stored as the degenerate box [1e30,1e30]^3: a min/max slab test treats an inverted box

@@ -79,19 +79,31 @@ def fused_activations(xyz, log_scales, rot_raw, opacity_logit, seg_start, poses)
     return _FusedActivations.apply(xyz, log_scales, rot_raw, opacity_logit, seg_start, poses)
 
 
+_SEG_CACHE = {}        # (device, counts) -> (segment starts, identity pose row, ones(1)): host->device copies wait for the stream, so they
+                       # are made once per asset layout, not per rendered frame
+
+
 def pack_poses(poses: Sequence[Tuple], counts: Sequence[int], device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Segment starts (A+1,) int32 and the (A,8) pose table from per-asset ``(t (3,), q (4,) or (1,4)) | None`` and sizes."""
-    A = len(counts)
-    seg = torch.zeros(A + 1, dtype=torch.int32)
-    seg[1:] = torch.cumsum(torch.tensor(list(counts), dtype=torch.int64), 0).to(torch.int32)
-    tab = torch.zeros(A, 8, dtype=torch.float32)
-    tab[:, 3] = 1.0
+    """Segment starts (A+1,) int32 and the (A,8) pose table from per-asset ``(t (3,), q (4,) or (1,4)) | None`` and sizes.
+    No host->device copy after the first call for an asset layout (pose tensors that already live on the device are only
+    concatenated there): the rendering loop stays stream-ordered."""
+    device = torch.device(device)
+    key = (str(device), tuple(int(c) for c in counts))
+    ent = _SEG_CACHE.get(key)
+    if ent is None:
+        A = len(counts)
+        seg = torch.zeros(A + 1, dtype=torch.int32)
+        seg[1:] = torch.cumsum(torch.tensor(list(counts), dtype=torch.int64), 0).to(torch.int32)
+        ident = torch.zeros(8, dtype=torch.float32); ident[3] = 1.0
+        if len(_SEG_CACHE) > 64:
+            _SEG_CACHE.clear()
+        ent = _SEG_CACHE[key] = (seg.to(device), ident.to(device), torch.ones(1, dtype=torch.float32, device=device))
+    seg, ident, one = ent
     rows = []
-    for a, ps in enumerate(poses):
+    for ps in poses:
         if ps is None:
-            rows.append(tab[a].to(device))
+            rows.append(ident)
         else:
             t, q = ps
-            rows.append(torch.cat([t.reshape(3).to(device, torch.float32), q.reshape(4).to(device, torch.float32),
-                                   torch.ones(1, device=device)]))
-    return seg.to(device), torch.stack(rows, 0).contiguous()
+            rows.append(torch.cat([t.reshape(3).to(device, torch.float32), q.reshape(4).to(device, torch.float32), one]))
+    return seg, torch.stack(rows, 0).contiguous()
