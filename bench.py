@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. fwd_mode=0, bwd_mode=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="owner", choices=["owner", "dense", "sparse", "auto"], help="gradient exchange for N > 1: owner = every "
+                    "Gaussian's gradient is reduced to its owning rank (one padded all_to_all of the touched rows, reduce-scatter semantics); "
+                    "dense = all_reduce of the flat buffer (replicated); sparse / auto = all_gather of the touched rows (replicated)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
                     "at least this long (one window, bracketed once; `steps` in the output is what ran, `steps_requested` what was asked); 0 = exactly --steps")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
@@ -165,7 +168,7 @@ def main():
     dL = torch.as_tensor(dL_np, device=dev)
 
     from lidar_rt_amd.parallel import ShardedTracer
-    tr = ShardedTracer()
+    tr = ShardedTracer(exchange=args.exchange)
     st = tr.backend.state
     for kv in args.opt:
         k_, v_ = kv.split("=")
@@ -224,6 +227,18 @@ def main():
     hs = st.get_stats(dev)
     st.enable_stats(False)
 
+    cks = None
+    if args.check_sum:
+        # owner exchange: a Gaussian's gradient is complete on its owner only -> sum over the owned rows, then over the ranks
+        def _abs_sum(x, rows=None):
+            x = x.double().abs().reshape(x.shape[0], -1)
+            return (x[rows] if rows is not None else x).sum()
+        own = (tr.last_owner == rank) if (world > 1 and tr.last_exchange == "owner") else None
+        vals = torch.stack([out.double().abs().sum(), _abs_sum(g["means"], own), _abs_sum(g["shs"], own),
+                            (g["accum"].double()[own] if own is not None else g["accum"].double()).sum()])
+        if own is not None:
+            part = vals[1:].clone(); dist.all_reduce(part, op=dist.ReduceOp.SUM); vals[1:] = part
+        cks = dict(zip(("out", "d_means", "d_shs", "accum"), [float(v) for v in vals.tolist()]))
     if rank == 0:
         n_rays = H * W
         ms_per_step = 1e3 * elapsed / steps_run
@@ -290,8 +305,7 @@ def main():
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }
         if args.check_sum:
-            res["checksums"] = {"out": float(out.double().abs().sum()), "d_means": float(g["means"].double().abs().sum()),
-                                "d_shs": float(g["shs"].double().abs().sum()), "accum": float(g["accum"].double().sum())}
+            res["checksums"] = cks
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(sc, ro, rd, deg, bg_np, dL_np)

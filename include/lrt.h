@@ -143,6 +143,23 @@ int lrt_grad_gather(int device, int P, int M, int n, const int32_t* idx, const f
 int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, const float* rows, float* d_means,
                          float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
 
+/* Owner-based exchange of the azimuth-sharded backward (not in the reference): every Gaussian has ONE owning rank -- the rank whose
+ * slab axis (mean ray direction, `axes` (N,3), unit vectors) is closest to the direction sensor `origin` -> Gaussian -- and a rank's
+ * partial gradient rows travel to the owner only (padded all-to-all, `cap` rows per (source, owner) pair), instead of every rank
+ * receiving every row.
+ *   lrt_owner_by_direction        owner[g] (int32) for all P Gaussians; the same on every rank (replicated inputs)
+ *   lrt_grad_pack_foreign         cnt[N] (zeroed here; keeps counting beyond cap), idx (N, cap), rows (N, cap, 11 + 3M) of the Gaussians
+ *                                 this rank touched (accum > 0) and does not own; row layout of lrt_grad_gather
+ *   lrt_grad_scatter_add_counted  add one received list (count on the device, at most cap rows) into the dense tensors
+ *   lrt_status_to_device          this state's error bits (last forward | sticky) as one float at a device address */
+int lrt_owner_by_direction(int device, int P, const float* means, const float* origin, int N, const float* axes, int32_t* owner, void* stream);
+int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, const int32_t* owner, const float* d_means, const float* d_scales,
+                          const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx,
+                          unsigned* cnt, float* rows, void* stream);
+int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, const float* rows, float* d_means,
+                                 float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
+int lrt_status_to_device(lrt_state* st, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,7 +91,7 @@ struct lrt_state {
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     // stream-ordered backward: when the forward's status words have not reached the host yet, the backward is enqueued with sizes
     // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
-    int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin; hipStream_t last_stream;
+    int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
@@ -301,6 +301,56 @@ __global__ void __launch_bounds__(256) k_grad_rows(int n, int width, const int32
     if (GATHER) rows[t] = *p; else *p += rows[t];
 }
 
+// Counted variants for the owner-based exchange: list l of `nlists` holds cnt[l] (device) rows of at most `cap`; thread = (list, row, column).
+template <bool GATHER>
+__global__ void __launch_bounds__(256) k_grad_rows_multi(int cap, int width, const unsigned* __restrict__ cnt, const int32_t* __restrict__ idx,
+                                                         GradFields g, float* rows, int skip_list)
+{
+    const int l = blockIdx.y;
+    if (l == skip_list) return;
+    const unsigned n = min(cnt[l], (unsigned)cap);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * width) return;
+    const int r = (int)(t / width);
+    int e = (int)(t - (long long)r * width);
+    const int gi = idx[(size_t)l * cap + r];
+    int k = 0;
+    while (e >= g.w[k]) { e -= g.w[k]; k++; }
+    float* p = g.f[k] + (size_t)gi * g.w[k] + e;
+    float* q = rows + ((size_t)l * cap + r) * width + (t - (long long)r * width);
+    if (GATHER) *q = *p; else *p += *q;
+}
+
+// owner[g] = the rank whose slab axis is closest to the direction sensor -> Gaussian (ties: the lowest rank)
+__global__ void __launch_bounds__(256) k_owner(int P, const float* __restrict__ means, const float* __restrict__ origin, int N,
+                                               const float* __restrict__ axes, int32_t* __restrict__ owner)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const float vx = means[3 * (size_t)g] - origin[0], vy = means[3 * (size_t)g + 1] - origin[1], vz = means[3 * (size_t)g + 2] - origin[2];
+    float best = -3.0e38f; int bk = 0;
+    for (int k = 0; k < N; k++) {
+        const float dp = vx * axes[3 * k] + vy * axes[3 * k + 1] + vz * axes[3 * k + 2];
+        if (dp > best) { best = dp; bk = k; }
+    }
+    owner[g] = bk;
+}
+
+// Gaussians this rank touched (accum > 0) but does not own: appended to the index list of their owner (at most cap per owner;
+// cnt keeps counting beyond cap so that the receiver and the host see the overflow)
+__global__ void __launch_bounds__(256) k_list_foreign(int P, int rank, int cap, const int32_t* __restrict__ owner, const float* __restrict__ accum,
+                                                      int32_t* __restrict__ idx, unsigned* __restrict__ cnt)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const int d = owner[g];
+    if (d == rank || !(accum[g] > 0.f)) return;
+    const unsigned slot = atomicAdd(cnt + d, 1u);
+    if (slot < (unsigned)cap) idx[(size_t)d * cap + slot] = g;
+}
+
+__global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (float)(ctrl[10] | ctrl[12]); }
+
 #include "lrt_trace_legacy.inc"
 
 #include "lrt_collect.inc"
@@ -488,6 +538,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value != 0 && value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 (K-buffer packets) or 2 (collect & resolve, default); mode 1 was retired"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
+    if (!strcmp(name, "defer_errors")) { st->defer_errors = value ? 1 : 0; return LRT_OK; }   // 1: lrt_forward / lrt_backward do not report an overflow themselves (a sharded caller collects every rank's status and raises on all ranks alike); lrt_check_forward still does
     if (!strcmp(name, "spec_margin")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: spec_margin must be >= 0"); st->spec_margin = value; return LRT_OK; }   // hits added to the speculated size (tests set 0)
     if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
     if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
@@ -592,14 +643,75 @@ static int report_overflow(lrt_state* st, const char* fn, int code, hipStream_t 
              "for 1/2 use option fwd_mode=0", fn, code);
 }
 
+/* The error bits of this state (the last forward's and the sticky ones) as ONE float written to the device address `dst` on
+ * `stream`: a sharded caller sends it along with its slab so that every rank learns about every rank's overflow. */
+int lrt_status_to_device(lrt_state* st, float* dst, void* stream_)
+{
+    if (!st || !dst) LRT_FAIL(LRT_ERR_ARG, "lrt_status_to_device: null argument");
+    DeviceGuard dg(st->device);
+    hipLaunchKernelGGL(k_status_word, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const unsigned*)st->ctrl, dst);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+int lrt_owner_by_direction(int device, int P, const float* means, const float* origin, int N, const float* axes, int32_t* owner, void* stream_)
+{
+    if (P < 0 || N < 1 || (P > 0 && (!means || !origin || !axes || !owner))) LRT_FAIL(LRT_ERR_ARG, "lrt_owner_by_direction: bad argument");
+    if (P == 0) return LRT_OK;
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_owner_by_direction: cannot select HIP device %d", device);
+    hipLaunchKernelGGL(k_owner, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, means, origin, N, axes, owner);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+/* Owner-based gradient exchange, sender side: list the touched Gaussians of other owners (cnt[N] zeroed here, idx (N, cap)), then
+ * pack their rows (N, cap, 11 + 3M) -- the row layout of lrt_grad_gather.  cnt keeps counting beyond cap (overflow is visible). */
+int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, const int32_t* owner, const float* d_means, const float* d_scales,
+                          const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx,
+                          unsigned* cnt, float* rows, void* stream_)
+{
+    if (P < 0 || M < 0 || N < 1 || rank < 0 || rank >= N || cap < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_foreign: bad sizes");
+    if (!owner || !idx || !cnt || !rows || !accum) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_foreign: null pointer");
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_pack_foreign: cannot select HIP device %d", device);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)N * sizeof(unsigned), stream));
+    if (P == 0) return LRT_OK;
+    hipLaunchKernelGGL(k_list_foreign, dim3((P + 255) / 256), dim3(256), 0, stream, P, rank, cap, owner, accum, idx, cnt);
+    GradFields g; g.f[0] = const_cast<float*>(d_means); g.w[0] = 3; g.f[1] = const_cast<float*>(d_scales); g.w[1] = 2; g.f[2] = const_cast<float*>(d_rotations); g.w[2] = 4;
+    g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
+    const int width = 11 + 3 * M;
+    const long long per = (long long)cap * width;
+    hipLaunchKernelGGL(k_grad_rows_multi<true>, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, rank);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+/* Receiver side: add the rows of ONE source list (count on the device) into the dense tensors (unique indices inside a list: plain
+ * read-modify-write; call once per source in rank order for a deterministic sum). */
+int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, const float* rows, float* d_means,
+                                 float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream_)
+{
+    if (P < 0 || M < 0 || cap < 1 || !cnt_dev || !idx || !rows) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_scatter_add_counted: bad argument");
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_scatter_add_counted: cannot select HIP device %d", device);
+    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rotations; g.w[2] = 4; g.f[3] = d_opacities; g.w[3] = 1;
+    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
+    const int width = 11 + 3 * M;
+    const long long per = (long long)cap * width;
+    hipLaunchKernelGGL(k_grad_rows_multi<false>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, const_cast<float*>(rows), -1);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
 int lrt_check_forward(lrt_state* st, int wait)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_check_forward: null state");
-    if (!st->fwd_pending) return LRT_OK;
     DeviceGuard dg(st->device);
-    if (wait) HIPCHK(hipEventSynchronize(st->hit_ev));
-    else if (hipEventQuery(st->hit_ev) != hipSuccess) return LRT_OK;            // still running: ask again later (errors are sticky)
-    const int code = absorb_status(st);
+    if (st->fwd_pending) {
+        if (wait) HIPCHK(hipEventSynchronize(st->hit_ev));
+        else if (hipEventQuery(st->hit_ev) != hipSuccess) return LRT_OK;        // still running: ask again later (errors are sticky)
+        (void)absorb_status(st);
+    }
+    const int code = st->hit_ovf_host[4] | st->hit_ovf_host[2];               // also bits absorbed earlier without a report (defer_errors)
     if (code != 0) return report_overflow(st, "lrt_forward", code, st->last_stream);
     return LRT_OK;
 }
@@ -852,8 +964,10 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (P > 0 && (!shs || !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null shs/accum pointer");
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
-    rc = lrt_check_forward(st, 0);                                              // a finished earlier forward that overflowed is reported now
-    if (rc) return rc;
+    if (!st->defer_errors) {
+        rc = lrt_check_forward(st, 0);                                          // a finished earlier forward that overflowed is reported now
+        if (rc) return rc;
+    } else if (st->fwd_pending && hipEventQuery(st->hit_ev) == hipSuccess) (void)absorb_status(st);
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
@@ -1030,7 +1144,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
         st->last_bwd_spec = ready ? 0 : 1;
         if (ready) {
             const int code = absorb_status(st);
-            if (code != 0) return report_overflow(st, "lrt_backward", code, stream);
+            if (code != 0 && !st->defer_errors) return report_overflow(st, "lrt_backward", code, stream);
             n_hits = (unsigned)st->hit_ovf_host[1]; record_ok = st->hit_ovf_host[0] == 0;
         } else {
             unsigned long long g = (unsigned long long)st->est_hits + st->est_hits / 8 + (unsigned long long)st->spec_margin;

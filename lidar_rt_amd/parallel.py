@@ -2,19 +2,31 @@
 (not present in the reference, which is single-GPU).
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI;
-"gloo" on CPU for the tests).  Every rank holds the full Gaussian set and
-builds an identical read-only LBVH; rank r traces the contiguous column slab
-``[r*W/N, (r+1)*W/N)`` of the (H, W) range image.
+"gloo" on CPU for the tests).  Every rank holds the full Gaussian set; rank r
+traces the contiguous column slab ``[r*W/N, (r+1)*W/N)`` of the (H, W) range
+image.  From 3 ranks on a rank's LBVH holds only the Gaussians its slab's ray
+cone can reach (``lrt_build_for_rays``; a 180-degree slab has no useful cone).
 
-* forward : local slab -> ``all_gather`` of the (H, W/N, 9) slabs (4.7 MB at
-  64x2048, negligible) so every rank sees the whole image for image-space
-  losses; per-Gaussian hit weights are part of the fused reduction below.
-* backward: each rank scatters its partial gradients into ONE flat fp32 buffer
+* forward : local slab -> ONE ``all_gather`` of ``[status | (H, W/N, 9) slab]``
+  (4.7 MB at 64x2048) so every rank sees the whole image for image-space losses
+  -- and every rank's overflow status, see "errors" below.
+* backward: each rank's partial gradients live in ONE flat fp32 buffer
   ``[d_means | d_scales | d_rotations | d_opacities | d_shs | accum]``
-  (59 + 1 floats per Gaussian at M=16), reduced by ONE ``all_reduce`` (sum).
-  xGMI is a point-to-point mesh, so a single large collective lets RCCL use
-  all 7 links (reduce-scatter + all-gather); many small ones would be
-  latency-bound.
+  (59 + 1 floats per Gaussian at M=16).  Three exchanges:
+    - ``owner``  (what bench.py uses for N > 1): every Gaussian has ONE owning rank -- the rank whose slab axis is closest to the
+      direction sensor -> Gaussian -- and a rank's rows of touched Gaussians travel to their owner only: one padded
+      ``all_to_all`` with a fixed, speculated capacity per (source, owner) pair; no ``nonzero`` / ``tolist`` round trips.
+      Azimuth sectors touch mostly their own Gaussians, so a rank sends a few per cent of what it touched.  Result: the
+      gradient of Gaussian g is COMPLETE on ``owner[g]`` and meaningless elsewhere (``last_owner`` holds the map) -- the
+      shape a sector-sharded optimizer wants (reduce-scatter semantics).
+    - ``dense``  : one ``all_reduce`` of the flat buffer (replicated result; a single large message so that RCCL can use
+      all 7 xGMI links).
+    - ``sparse`` : replicated result through an ``all_gather`` of the touched rows (two small host round trips for the row
+      counts: kept for replicated optimizers, not used by the bench).
+* errors: the kernels raise device-side flags; a rank that raised alone would leave the others blocked in the next
+  collective.  Every rank therefore sends its status word with its slab (and the exchange its overflow counts with the
+  rows), keeps what it received in pinned memory, and ALL ranks raise the same ``LrtError`` at their next call into
+  ``ShardedTracer`` (or ``check()``) -- one step late, consistently, without a host wait in the step itself.
 
 The local tracer is injected (``backend``): the product default drives the HIP
 library; the CPU tests inject an oracle-backed stand-in to exercise the
@@ -22,7 +34,7 @@ collective logic with gloo (no GPU in CI).
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import os
 import torch
@@ -52,6 +64,10 @@ class GradLayout:
         if with_accum:
             self.views["accum"] = self.flat[o:o + P]; o += P
 
+    @property
+    def width(self) -> int:
+        return 11 + 3 * self.M
+
 
 class HipBackend:
     """Local tracer on this rank's GPU (the product path)."""
@@ -76,32 +92,63 @@ class HipBackend:
                                            mod, rotations, e, e, e, e, False, False, out, None, dL, grads_out=grads_out)
         return {"means": g[0], "shs": g[1], "opacities": g[3], "scales": g[4], "rotations": g[5]}
 
+    def defer_errors(self, on: bool = True):
+        """The library's forward / backward stop reporting overflows themselves: ShardedTracer gathers every rank's status and
+        raises on all ranks alike (a rank raising alone would leave the others blocked in the next collective)."""
+        self.state.set_option("defer_errors", 1 if on else 0)
+
+    def status_to(self, dst: torch.Tensor):
+        """This rank's error bits (last forward | sticky) as one float at dst[0] (device), stream-ordered."""
+        import ctypes as C
+        from . import _capi
+        idx, h = self.state.handle(dst.device)
+        with torch.cuda.device(idx):
+            _capi.check(self.state._lib.lrt_status_to_device(h, _capi.ptr(dst), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "lrt_status_to_device")
+
+    def clear_errors(self, device):
+        """Consume the library's own (sticky) report of an overflow that ShardedTracer reports for all ranks."""
+        from . import _capi
+        try:
+            self.state.check(device, wait=True)
+        except _capi.LrtError:
+            pass
+
 
 class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
     def __init__(self, backend=None, group=None, exchange: str = "auto"):
-        """exchange: "dense" = one all_reduce of the flat gradient buffer; "sparse" = all_gather of the rows of the
-        Gaussians each rank's rays touched (azimuth sectors touch mostly disjoint Gaussians); "auto" = sparse unless the
-        ranks together touched more than `sparse_max_fraction` of the Gaussians."""
-        if exchange not in ("auto", "dense", "sparse"):
-            raise ValueError("exchange must be 'auto', 'dense' or 'sparse'")
+        """exchange: "owner" = rows of touched Gaussians go to their owning rank (complete gradient on the owner only); "dense" = one
+        all_reduce of the flat gradient buffer (replicated); "sparse" = all_gather of the touched rows (replicated); "auto" = sparse
+        unless the ranks together touched more than `sparse_max_fraction` of the Gaussians, then dense."""
+        if exchange not in ("auto", "dense", "sparse", "owner"):
+            raise ValueError("exchange must be 'auto', 'dense', 'sparse' or 'owner'")
         self.exchange = exchange
         self.sparse_max_fraction = 0.6
-        self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | None
+        self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | "owner" | None
+        self.last_owner: Optional[torch.Tensor] = None  # (P,) int32 owner map of the last "owner" exchange
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # build the LBVH for this rank's rays only (lrt_build_for_rays; meaningful from 3 ranks on).  The library sizes the sort
-        # and the tree from the previous frame's kept count, so no read-back stalls the launch queue; on S1M the culled build
-        # beats the full one from ~1/8 of the frame per rank on (N=8: 0.25 -> 0.19-0.22 ms; N=4: 0.25 -> 0.27 ms), hence the
-        # default: on for 8 ranks and more
-        self.cull_build = self.world >= 8
+        # build the LBVH for this rank's rays only (lrt_build_for_rays).  The library sizes the sort and the tree from the previous
+        # frame's kept count, so no read-back stalls the launch queue; a slab of a third of the sweep (120 degrees) is the widest
+        # whose ray cone culls anything (the cull keeps everything beyond ~80 degrees of half angle)
+        self.cull_build = self.world >= 3
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
+        if self.world > 1 and hasattr(self.backend, "defer_errors"):
+            self.backend.defer_errors(True)
+        self.force_collectives = False # test hook: run the collective code paths with a world of one rank too (RCCL pre-flight)
         self._phase_on = False
         self._phase_ev = []            # (name, start event, end event) of the collectives' regions, read back by phase_timing()
+        self._pending = []             # [(what, pinned host tensor, event or None)] status words received from all ranks, not yet looked at
+        self._cap = None               # rows per (source, owner) pair of the owner exchange (speculated from earlier steps)
+        self._cap_key = None
+        self._worst_dev = None         # (1,) float32 on the device: largest row count of this rank's last owner exchange
+        self._worst_cap = 0            # ... and the capacity that exchange ran with
+        self._counts = []              # [(pinned (N,) counts of all ranks, event, capacity of that exchange)] not yet absorbed
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True):
@@ -128,6 +175,72 @@ class ShardedTracer:
         self._phase_ev = []
         return {k: float(sum(v) / len(v)) for k, v in acc.items()}
 
+    # ---- consistent error reporting -------------------------------------------------------------------------------------------
+    def _remember(self, what: str, dev_values: torch.Tensor):
+        """Keep status words that ALL ranks received identically; they are looked at by the next call (no wait now)."""
+        if dev_values.is_cuda:
+            host = torch.empty(dev_values.shape, dtype=dev_values.dtype, pin_memory=True)
+            host.copy_(dev_values, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            self._pending.append((what, host, ev))
+        else:
+            self._pending.append((what, dev_values.clone(), None))
+
+    def _remember_counts(self, dev_counts: torch.Tensor, cap_used: int):
+        if dev_counts.is_cuda:
+            host = torch.empty(dev_counts.shape, dtype=dev_counts.dtype, pin_memory=True)
+            host.copy_(dev_counts, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+        else:
+            host, ev = dev_counts.clone(), None
+        self._counts.append((host, ev, cap_used))
+
+    def _absorb_counts(self):
+        """Row counts of earlier owner exchanges that have reached the host: the largest sizes the next exchange (the same data
+        and the same rule on every rank, so every rank arrives at the same capacity); a count beyond the capacity it ran with is an
+        overflow, reported by check() like the forward's."""
+        for host, ev, cap_used in self._counts:
+            if ev is not None:
+                ev.synchronize()                       # recorded a step ago; every rank absorbs the same set (never skip one: the
+                                                       # capacities of all ranks must stay equal)
+            biggest = int(host.max().item())
+            if cap_used and biggest > cap_used:
+                self._pending.append(("exchange", torch.tensor([float(biggest), float(cap_used)]), None))
+                self._cap = None
+            elif self._cap is not None:
+                want = biggest + biggest // 4 + 1024
+                if want > self._cap or want < self._cap // 2:
+                    self._cap = want
+        self._counts = []
+
+    def check(self, wait: bool = True):
+        """Raise on EVERY rank alike if any rank reported an overflow in a step whose status has arrived (wait=True: in all
+        earlier steps).  Called at the start of forward()."""
+        if wait:
+            self._absorb_counts()
+        still = []
+        bad = None
+        for what, host, ev in self._pending:
+            if ev is not None and not wait and not ev.query():
+                still.append((what, host, ev)); continue
+            if ev is not None:
+                ev.synchronize()
+            vals = host.reshape(-1).tolist()
+            if any(v != 0 for v in vals) and bad is None:
+                bad = (what, vals)
+        self._pending = still
+        if bad is not None:
+            from ._capi import LrtError
+            if hasattr(self.backend, "clear_errors") and getattr(self, "_dev", None) is not None and self._dev.type == "cuda":
+                self.backend.clear_errors(self._dev)
+            what, vals = bad
+            if what == "exchange":
+                self._cap = None                               # next exchange sizes itself from the true counts again
+            raise LrtError(f"sharded tracer: a rank reported an overflow in an earlier step ({what}; per-rank words {vals}); that step's "
+                           "results are incomplete on it.  forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
+                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly); exchange: "
+                           "rows beyond the speculated capacity (the next exchange is sized exactly)")
+
     @staticmethod
     def _backend_takes(fn, name: str) -> bool:
         """Capability of an injected backend, from its signature (a TypeError raised INSIDE the backend must not be mistaken for
@@ -139,15 +252,18 @@ class ShardedTracer:
             return False
         return name in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
 
+    # ---- forward ----------------------------------------------------------------------------------------------------------------
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
         H, W = ray_o.shape[:2]
+        self._dev = means.device
+        if self.world > 1 or self.force_collectives:
+            self.check(wait=True)                              # statuses and counts of the previous step: long there; all ranks agree
         a, b = column_slab(W, self.rank, self.world)
         self._slab = (a, b)
         self._ro = ray_o[:, a:b].contiguous(); self._rd = ray_d[:, a:b].contiguous()
-        # a rank only needs the Gaussians its slab's rays can reach: optionally (cull_build) the LBVH is built for the slab's ray
-        # cone from 3 ranks on (slabs narrower than ~120 degrees); such a structure must be rebuilt for every ray set
+        self._rays_full = (ray_o, ray_d)
         cull = (self._ro, self._rd) if (self.world >= 3 and self.cull_build) else None
-        if rebuild or cull is not None:
+        if rebuild or cull is not None:                        # a ray-culled structure must be rebuilt for every ray set
             if self._backend_takes(self.backend.build, "cull_rays"):
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)
             else:                                                                 # backend without culling (test stand-ins)
@@ -155,21 +271,30 @@ class ShardedTracer:
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
         self._out_loc, self._accum_loc = out_loc, accum_loc
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
-        # all_gather needs equal shapes: pad slabs to the widest one
-        wmax = max(column_slab(W, r, self.world)[1] - column_slab(W, r, self.world)[0] for r in range(self.world))
+        # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
         with self._Region(self, "slab_all_gather", out_loc.device):
-            pad = torch.zeros((H, wmax, 9), dtype=out_loc.dtype, device=out_loc.device)
-            pad[:, :b - a] = out_loc
-            parts = self._all_gather_rows(pad)               # one flat receive buffer with RCCL
+            wmax = max(column_slab(W, r, self.world)[1] - column_slab(W, r, self.world)[0] for r in range(self.world))
+            msg = torch.zeros(2 + H * wmax * 9, dtype=out_loc.dtype, device=out_loc.device)
+            msg[2:].view(H, wmax, 9)[:, :b - a] = out_loc
+            if hasattr(self.backend, "status_to") and out_loc.is_cuda:
+                self.backend.status_to(msg)                  # word 0: this rank's forward / build status bits
+            if self._worst_dev is not None:
+                msg[1:2] = self._worst_dev                   # word 1: the largest row count of this rank's previous owner exchange
+            parts = self._all_gather_rows(msg)               # one flat receive buffer with RCCL
             cols = []
             for r in range(self.world):
                 ra, rb = column_slab(W, r, self.world)
-                cols.append(parts[r][:, :rb - ra])
+                cols.append(parts[r][2:].view(H, wmax, 9)[:, :rb - ra])
             full = torch.cat(cols, dim=1)
-        return full, accum_loc                          # accum is completed by backward()'s fused reduction
+            hdr = torch.stack([p[:2] for p in parts])        # (N, 2), identical on every rank
+            self._remember("forward", hdr[:, 0])
+            if self._worst_dev is not None:
+                self._remember_counts(hdr[:, 1], self._worst_cap)
+        return full, accum_loc                          # accum is completed by backward()'s exchange
 
+    # ---- backward ---------------------------------------------------------------------------------------------------------------
     def backward(self, means, scales, rotations, opacities, shs, deg, bg, dL_full, mod=1.0,
                  reduce: bool = True) -> Dict[str, torch.Tensor]:
         a, b = self._slab
@@ -189,9 +314,12 @@ class ShardedTracer:
                 direct[k].copy_(g[k].view_as(direct[k]))
         lay.views["accum"].copy_(self._accum_loc)
         self.last_exchange = None
-        if reduce and self.world > 1:
+        if reduce and (self.world > 1 or self.force_collectives):
             with self._Region(self, "gradient_exchange", lay.flat.device):
-                if self.exchange == "dense" or not self._exchange_sparse(lay):
+                mode = self.exchange
+                if mode == "owner":
+                    self._exchange_owner(lay, means)
+                elif mode == "dense" or not self._exchange_sparse(lay):
                     dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
                     self.last_exchange = "dense"
         return lay.views
@@ -203,31 +331,141 @@ class ShardedTracer:
         from . import _capi
         v, p = lay.views, _capi.ptr
         dev = rows.device
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         dense = (p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]))
         lib = _capi.load()
-        if fn == "lrt_grad_gather":
-            rc = lib.lrt_grad_gather(idx, lay.P, lay.M, int(n), p(ids), *dense, p(rows), stream)
-        else:
-            rc = lib.lrt_grad_scatter_add(idx, lay.P, lay.M, int(n), p(ids), p(rows), *dense, stream)
+        with torch.cuda.device(idx):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if fn == "lrt_grad_gather":
+                rc = lib.lrt_grad_gather(idx, lay.P, lay.M, int(n), p(ids), *dense, p(rows), stream)
+            else:
+                rc = lib.lrt_grad_scatter_add(idx, lay.P, lay.M, int(n), p(ids), p(rows), *dense, stream)
         _capi.check(rc, fn)
 
     def _all_gather_rows(self, t: torch.Tensor):
         """all_gather of equally shaped tensors; one flat receive buffer when the backend offers it (RCCL), so that the
         collective is a single large message without a per-rank copy."""
         world = self.world
-        if t.is_cuda:
-            try:
-                out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() > 0 else out, t, group=self.group)
-                return [out[r] for r in range(world)]
-            except (RuntimeError, NotImplementedError, AttributeError):
-                pass                                                  # e.g. gloo with device tensors: fall through
+        if t.is_cuda and dist.get_backend(self.group) == "nccl":
+            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() > 0 else out, t.contiguous(), group=self.group)
+            return [out[r] for r in range(world)]
         parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=self.group)
+        dist.all_gather(parts, t.contiguous(), group=self.group)
         return parts
 
+    # ---- owner-based exchange ---------------------------------------------------------------------------------------------------
+    def slab_axes(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(origin (3,), axes (N,3)): the frame's sensor origin (mean ray origin) and the unit mean ray direction of every rank's
+        slab -- every rank computes all of them from the full ray grid, on the device."""
+        ray_o, ray_d = self._rays_full
+        W = ray_o.shape[1]
+        origin = ray_o.reshape(-1, 3).mean(0)
+        axes = []
+        for r in range(self.world):
+            ra, rb = column_slab(W, r, self.world)
+            d = ray_d[:, ra:rb].reshape(-1, 3)
+            m = (d / d.norm(dim=1, keepdim=True).clamp_min(1e-30)).mean(0)
+            axes.append(m / m.norm().clamp_min(1e-30))
+        return origin.contiguous(), torch.stack(axes, 0).contiguous()
+
+    def owner_map(self, means: torch.Tensor) -> torch.Tensor:
+        """owner[g] (int32): the rank whose slab axis is closest to the direction sensor -> Gaussian g (ties: the lowest rank)."""
+        origin, axes = self.slab_axes()
+        P = means.shape[0]
+        if means.is_cuda:
+            import ctypes as C
+            from . import _capi
+            owner = torch.empty(P, dtype=torch.int32, device=means.device)
+            idx = means.device.index if means.device.index is not None else torch.cuda.current_device()
+            m = means.detach().contiguous()
+            with torch.cuda.device(idx):
+                _capi.check(_capi.load().lrt_owner_by_direction(idx, P, _capi.ptr(m), _capi.ptr(origin), self.world, _capi.ptr(axes),
+                                                                _capi.ptr(owner), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                            "lrt_owner_by_direction")
+            return owner
+        return ((means.detach() - origin) @ axes.T).argmax(1).to(torch.int32)     # torch's argmax also returns the first maximum
+
+    def _exchange_owner(self, lay: GradLayout, means: torch.Tensor):
+        """Rows of touched Gaussians go to their owner: ONE all_to_all of ``N x [count | cap indices | cap rows]`` per rank.
+        The capacity per (source, owner) pair is speculated from the previous exchange's largest count (x1.25 + 1024); the true
+        counts travel with the rows, land in pinned memory and size the next step; an overflow is reported by check()."""
+        P, M, N, rank = lay.P, lay.M, self.world, self.rank
+        width = lay.width
+        dev = lay.flat.device
+        owner = self.owner_map(means)
+        self.last_owner = owner
+        key = (P, M, N)
+        if self._cap_key != key:
+            self._cap, self._cap_key, self._counts, self._worst_dev = None, key, [], None
+        # NOTE: every rank must arrive at the same capacity: it only depends on data that all ranks share (the all-gathered counts)
+        # and on which of them have reached the host -- absorbed in forward(), right after check(), where all ranks wait alike
+        if self._cap is None:
+            # first exchange of this size (or after an overflow): the exact counts, one host wait
+            foreign = (lay.views["accum"] > 0) & (owner != rank)
+            mine = torch.bincount(owner[foreign].long(), minlength=N).max().reshape(1)
+            allc = torch.stack(self._all_gather_rows(mine)).max()
+            c = int(allc.item())
+            self._cap = c + c // 4 + 1024
+        cap = min(self._cap, max(P, 1))
+        blk = 1 + cap + cap * width                                   # floats per (source, owner) block: count | indices | rows
+        cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+        idx = torch.empty((N, cap), dtype=torch.int32, device=dev)
+        rows = torch.empty((N, cap, width), dtype=torch.float32, device=dev)
+        v = lay.views
+        if dev.type == "cuda":
+            import ctypes as C
+            from . import _capi
+            p = _capi.ptr
+            di = dev.index if dev.index is not None else torch.cuda.current_device()
+            with torch.cuda.device(di):
+                _capi.check(_capi.load().lrt_grad_pack_foreign(di, P, M, N, rank, cap, p(owner), p(v["means"]), p(v["scales"]), p(v["rotations"]),
+                                                               p(v["opacities"]), p(v["shs"]), p(v["accum"]), p(idx), p(cnt), p(rows),
+                                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_grad_pack_foreign")
+        else:
+            touched = (v["accum"] > 0)
+            for d in range(N):
+                if d == rank:
+                    continue
+                g = torch.nonzero(touched & (owner == d)).squeeze(1)
+                cnt[d] = g.numel()
+                g = g[:cap]
+                idx[d, :g.numel()] = g.to(torch.int32)
+                col = 0
+                for name, k in list(GradLayout.FIELDS) + [("shs", 3 * M), ("accum", 1)]:
+                    rows[d, :g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
+                    col += k
+        # one int32 message per (source, owner) pair: count | cap indices | cap rows (bit patterns of the floats)
+        send = torch.cat([cnt.view(N, 1), idx, rows.view(torch.int32).reshape(N, cap * width)], dim=1).contiguous()
+        assert send.shape[1] == blk
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        rcnt = recv[:, 0].contiguous()
+        ridx = recv[:, 1:1 + cap].contiguous()
+        rrows = recv[:, 1 + cap:].contiguous().view(torch.float32).view(N, cap, width)
+        for s in range(N):                                            # fixed order of the sources -> a deterministic sum
+            if s == rank:
+                continue
+            if dev.type == "cuda":
+                with torch.cuda.device(di):
+                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(rcnt[s:s + 1]), p(ridx[s]), p(rrows[s]), p(v["means"]),
+                                                                          p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]),
+                                                                          p(v["accum"]), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                "lrt_grad_scatter_add_counted")
+            else:
+                c = min(int(rcnt[s]), cap)
+                g = ridx[s, :c].long()
+                col = 0
+                for name, k in list(GradLayout.FIELDS) + [("shs", 3 * M), ("accum", 1)]:
+                    v[name].view(P, k).index_add_(0, g, rrows[s, :c, col:col + k])
+                    col += k
+        # the largest count this rank saw (sent or received) travels with the next forward's slab message to every rank: it sizes
+        # later exchanges and exposes an overflow of this one
+        self._worst_dev = torch.maximum(cnt.max(), rcnt.max()).to(torch.float32).reshape(1)
+        self._worst_cap = cap
+        self.last_exchange = "owner"
+
+    # ---- replicated sparse exchange ---------------------------------------------------------------------------------------------
     def _exchange_sparse(self, lay: GradLayout) -> bool:
         """Sum the ranks' partial gradients by exchanging only the rows of touched Gaussians.
 

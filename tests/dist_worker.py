@@ -23,17 +23,20 @@ def main():
     dL = scenes.upstream_grad(6, 45)
     t = {k: torch.from_numpy(v) for k, v in sc.items()}
     bg = torch.tensor([0.0, 0.0, 1.0])
-    want = "dense" if exchange in ("dense", "auto-dense") else "sparse"
+    want = "dense" if exchange in ("dense", "auto-dense") else ("owner" if exchange == "owner" else "sparse")
     tr = ShardedTracer(backend=OracleBackend(), exchange="auto" if exchange == "auto-dense" else exchange)
     if exchange == "auto-dense":
         tr.sparse_max_fraction = 0.0                  # "auto" must fall back to the dense all_reduce (decided identically on every rank)
-    out, _ = tr.forward(torch.from_numpy(o), torch.from_numpy(d), t["means"], t["scales"], t["rotations"],
-                        t["opacities"], t["shs"], 3, bg)
-    g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, torch.from_numpy(dL))
+    for step in range(3 if exchange == "owner" else 1):   # owner: exact capacity first, then capacities speculated from the counts
+        out, _ = tr.forward(torch.from_numpy(o), torch.from_numpy(d), t["means"], t["scales"], t["rotations"],
+                            t["opacities"], t["shs"], 3, bg)
+        g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, torch.from_numpy(dL))
+    tr.check()
     a, b = column_slab(45, rank, world)
     assert tr._slab == (a, b)
     assert tr.last_exchange == want, tr.last_exchange
-    np.savez(out_path + f".rank{rank}.npz", out=out.numpy(), **{k: v.numpy() for k, v in g.items()})
+    extra = {"owner": tr.last_owner.numpy()} if exchange == "owner" else {}
+    np.savez(out_path + f".rank{rank}.npz", out=out.numpy(), **{k: v.numpy() for k, v in g.items()}, **extra)
     dist.barrier()
     dist.destroy_process_group()
 

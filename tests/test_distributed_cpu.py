@@ -33,7 +33,7 @@ def test_grad_layout_is_one_flat_buffer():
     assert float(lay.flat.sum()) == 10 * 48 * 2.0 + 10 * 3.0
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "auto"), (2, "auto-dense")])
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "auto"), (2, "auto-dense"), (2, "owner"), (3, "owner")])
 def test_sharded_equals_single(tmp_path, world, exchange):
     sc = scenes.make_scene(1500, seed=4, radius_scale=0.2)
     o, d = scenes.kitti_rays(6, 45)
@@ -50,6 +50,19 @@ def test_sharded_equals_single(tmp_path, world, exchange):
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), os.path.join(REPO, "tests", "dist_worker.py"), base, exchange]
     subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=600)
     res0 = np.load(base + ".rank0.npz")
+    if exchange == "owner":
+        # every Gaussian's gradient is complete on its owner (and only there); all ranks agree on the owner map
+        owners = res0["owner"]
+        assert set(np.unique(owners)) <= set(range(world)) and len(np.unique(owners)) == world
+        for r in range(world):
+            res = np.load(base + f".rank{r}.npz")
+            np.testing.assert_array_equal(res["owner"], owners)
+            np.testing.assert_allclose(res["out"], out1.numpy(), rtol=1e-6, atol=1e-7)
+            mine = owners == r
+            for k in ("means", "scales", "rotations", "opacities", "shs", "accum"):
+                ref = g1[k].numpy()
+                np.testing.assert_allclose(res[k][mine], ref[mine], rtol=1e-4, atol=1e-6 * max(np.abs(ref).max(), 1e-30))
+        return
     for r in range(world):
         res = np.load(base + f".rank{r}.npz")
         for k in ("means", "scales", "rotations", "opacities", "shs", "accum"):

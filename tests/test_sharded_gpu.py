@@ -19,7 +19,7 @@ def _bench(world, **extra_env):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(REPO, "bench.py")]
-    cmd += ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "s10k", "--no-cpu-baseline", "--check-sum"]
+    cmd += ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "s10k", "--no-cpu-baseline", "--check-sum", "--min-seconds", "0"]
     out = subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=600, capture_output=True, text=True).stdout
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
@@ -27,15 +27,54 @@ def _bench(world, **extra_env):
 def test_two_ranks_on_one_gpu_match_single_rank():
     a, b = _bench(1), _bench(2)
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
-    assert b["config"]["gradient_exchange"] == "sparse"               # all_gather of the touched rows, packed / added by the HIP kernels
+    assert b["config"]["gradient_exchange"] == "owner"                # rows of touched Gaussians to their owning rank (HIP pack / add kernels)
     for k in ("out", "d_means", "d_shs", "accum"):
         assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (k, a["checksums"], b["checksums"])
 
 
 def test_three_ranks_with_ray_culled_builds_match_single_rank():
-    """The N >= 8 default (every rank builds the LBVH for its own slab's rays, sized speculatively from the previous frame)
+    """The default from three ranks on (every rank builds the LBVH for its own slab's rays, sized speculatively from the previous frame)
     end to end through ShardedTracer, forced on at three ranks."""
     a, b = _bench(1), _bench(3, LRT_CULL_BUILD="1")
     assert b["n_gpus"] == 3
     for k in ("out", "d_means", "d_shs", "accum"):
         assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (k, a["checksums"], b["checksums"])
+
+
+def test_replicated_exchanges_on_one_gpu_match_single_rank():
+    a = _bench(1)
+    for ex in ("sparse", "dense"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", LRT_SINGLE_DEVICE="1", LRT_DIST_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+               os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "s10k", "--no-cpu-baseline", "--check-sum",
+               "--min-seconds", "0", "--exchange", ex]
+        out = subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=600, capture_output=True, text=True).stdout
+        b = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        assert b["config"]["gradient_exchange"] == ex
+        for k in ("out", "d_means", "d_shs", "accum"):
+            assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (ex, k)
+
+
+def test_rccl_preflight_world_of_one():
+    """The collectives of ShardedTracer on the backend they were written for: backend "nccl" (= RCCL) with ONE rank, every exchange
+    mode, collective code paths forced on.  all_gather_into_tensor / all_reduce / all_to_all_single execute on the driver's box at least
+    once; the results equal the plain single-rank ones."""
+    worker = os.path.join(REPO, "tests", "nccl_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, worker], check=True, env=env, cwd=REPO, timeout=600, capture_output=True, text=True).stdout
+    res = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert res["backend"] == "nccl" and set(res["exchanges"]) == {"owner", "dense", "sparse"}
+    assert all(v < 1e-6 for v in res["rel_err"].values()), res
+
+
+def test_an_overflow_on_one_rank_is_raised_by_all_ranks():
+    """A device-side overflow on ONE rank (its speculatively sized ray-culled build loses primitives) must not leave the other ranks
+    blocked in a collective: the status words travel with the slabs, and every rank raises at its next call -- the same step on all
+    ranks -- then carries on."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", "29619",
+           os.path.join(REPO, "tests", "overflow_worker.py")]
+    out = subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=120, capture_output=True, text=True).stdout
+    logs = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])["logs"]
+    assert logs[0] == logs[1] == logs[2], logs                      # every rank saw the same sequence: nobody hung, nobody raised alone
+    assert logs[0].count("raised") == 1 and logs[0][:3] == ["ok", "ok", "ok"] and logs[0][-1] == "clean", logs
