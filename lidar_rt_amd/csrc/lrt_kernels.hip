@@ -91,7 +91,7 @@ struct lrt_state {
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     // stream-ordered backward: when the forward's status words have not reached the host yet, the backward is enqueued with sizes
     // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
-    int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream;
+    int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream; int* near_list; size_t near_cap;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
     int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
@@ -144,6 +144,8 @@ struct TraceParams {
     float slab0; int* err_flag; float* cr_lists;
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
     float* tile_w0;        // k_fwd_cr4: per tile, the first-slab width learnt in the previous frame (0 = none yet)
+    // rays with a quad closer than LRT_T_NEAR: listed by the trace kernel, resolved by k_fwd_near (the reference's stale-slot rule)
+    int* near_list; unsigned* near_count;
     unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
 };
 
@@ -355,6 +357,7 @@ __global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restri
 
 #include "lrt_collect.inc"
 #include "lrt_collect4.inc"
+#include "lrt_near.inc"
 
 __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 {
@@ -505,7 +508,7 @@ void lrt_destroy(lrt_state* st)
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
     (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0);
-    (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev);
+    (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
     delete st;
 }
@@ -980,6 +983,13 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     st->hits_valid = 0; st->fast_valid = 0;
     st->fwd_serial++;
     const size_t HW = (size_t)H * W;
+    if (HW > st->near_cap) {
+        HIPCHK(hipStreamSynchronize(stream));
+        (void)hipFree(st->near_list); st->near_list = nullptr; st->near_cap = 0;
+        HIPCHK(hipMalloc(&st->near_list, HW * sizeof(int)));
+        st->near_cap = HW;
+    }
+    tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
     const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
@@ -1075,6 +1085,8 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
                 else hipLaunchKernelGGL((k_fwd_cr4<false, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
             }
+            // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
+            hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
             if (dfr) {
                 const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
@@ -1085,6 +1097,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         rc = launch_trace(st, tp, false, stream);
         if (rc) return rc;
         tp.ovf_list = nullptr;
+        if (HW > 0 && P > 0) hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
     }
     // epilogue: colours of the hits beyond the record (deferred colour), status words -> host-mapped block, sticky error bits
     hipLaunchKernelGGL(k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);

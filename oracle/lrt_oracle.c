@@ -12,6 +12,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Test switch: feed the any-hit program in ascending order of t instead of BVH traversal order.  The order only matters for rays
+ * with a stale K-buffer slot (a hit closer than 0.2 m, forward.cu:214): there the reference's `cnt` -- hence which hits a chunk looks
+ * at -- depends on the order in which OptiX happens to report the hits; ascending order is the realisation the HIP path replays. */
+static int g_sorted_anyhit = 0;
+void orc_set_sorted_anyhit(int on) { g_sorted_anyhit = on; }
+
 #define REAL float
 #define SFX(n) n##_f32
 #define R_SQRT sqrtf

@@ -140,6 +140,12 @@ def sh_basis(deg, dirs, prec="f64"):
     return b
 
 
+def set_sorted_anyhit(on: bool) -> None:
+    """Feed the any-hit program in ascending t instead of BVH order (matters only for rays with a hit closer than 0.2 m: the
+    reference's stale-slot behaviour is order-dependent there; this is the realisation the HIP path replays)."""
+    lib().orc_set_sorted_anyhit(C.c_int(1 if on else 0))
+
+
 def num_threads() -> int:
     return int(lib().orc_num_threads())
 
