@@ -87,10 +87,16 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 int sh_degree, const float* shs, const float* background, int training, float* out9,
                 int32_t* out_i32, float* accum, void* stream);
 
-/* Backward trace: re-traces like the reference (backward.cu:513) and scatters the analytic gradients.
+/* Backward trace (TraceSurfelsBackwardCUDA).  After a forward with training != 0 on the same state it replays that forward's
+ * composited-hit record (per-ray preparation -> radix sort by Gaussian -> segmented reduction); otherwise it re-traces like the
+ * reference (backward.cu:513) and scatters with atomics.
  *   means/scales/rotations/opacities: the same parameter tensors given to lrt_build.
  *   out9: forward output; dL_dout9 (H,W,9): upstream gradient.
- *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): zero-filled, then accumulated. */
+ *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): zero-filled, then accumulated.
+ * Stream order: the call does not wait for the forward.  If the forward's status (its composited-hit count) has not reached the
+ * host yet, the sort is sized from the last completed forward of the same image size (x 1.125 + 64 k) and the kernels decide on
+ * the device between the sorted reduction and the re-tracing fallback (both enqueued; the one not needed returns at once).  Only
+ * the first backward of an image size waits for its forward (option "spec_bwd" = 0: every backward does). */
 int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M,
                  int sh_degree, const float* means, const float* scales, const float* rotations,
                  const float* opacities, const float* shs, const float* background, const float* out9,
@@ -105,9 +111,12 @@ long long lrt_forward_serial(lrt_state* st);
 /* Primitives in the current LBVH (= P after lrt_build, the kept count after lrt_build_for_rays; -1: nothing built). */
 int lrt_built_count(lrt_state* st);
 
-/* Overflow status of the most recent lrt_forward (the kernels only raise a device flag; lrt_backward checks it too).
- * wait != 0: block until that forward has finished; wait == 0: report only if it already has.  Returns LRT_ERR_STATE with
- * a message when its output is incomplete.  lrt_forward calls this (wait = 0) for the previous call. */
+/* Overflow status.  The trace kernels raise device-side bits (1 = candidate list, 2 = BVH queue / stack, 4 = colour overflow list,
+ * 8 = a speculatively sized ray-culled build lost primitives); the bits are STICKY on the device until the host has reported them,
+ * so a host that runs several frames ahead still learns about every overflow.  wait != 0: block until the most recent forward has
+ * finished; wait == 0: look only at what has already arrived.  Returns LRT_ERR_STATE with a message once per overflow.
+ * lrt_forward and lrt_backward call this themselves (wait = 0) unless option "defer_errors" is set (sharded callers, which
+ * propagate lrt_status_to_device to all ranks and raise on all of them alike). */
 int lrt_check_forward(lrt_state* st, int wait);
 
 /* Optional instrumentation: when enabled, lrt_forward accumulates

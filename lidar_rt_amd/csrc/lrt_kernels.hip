@@ -455,7 +455,7 @@ struct ScopedTimer {
 
 extern "C" {
 
-int lrt_abi_version(void) { return 1; }
+int lrt_abi_version(void) { return 2; }
 const char* lrt_last_error(void) { return g_err; }
 // the same buffer for the other translation units of this library (lrt_chamfer.hip); not part of the ABI
 __attribute__((visibility("hidden"))) char* lrt_internal_errbuf(void) { return g_err; }

@@ -4,8 +4,8 @@
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI;
 "gloo" on CPU for the tests).  Every rank holds the full Gaussian set; rank r
 traces the contiguous column slab ``[r*W/N, (r+1)*W/N)`` of the (H, W) range
-image.  From 3 ranks on a rank's LBVH holds only the Gaussians its slab's ray
-cone can reach (``lrt_build_for_rays``; a 180-degree slab has no useful cone).
+image.  From 8 ranks on a rank's LBVH holds only the Gaussians its slab's ray
+cone can reach (``lrt_build_for_rays``; below that the cull costs more than it saves).
 
 * forward : local slab -> ONE ``all_gather`` of ``[status | (H, W/N, 9) slab]``
   (4.7 MB at 64x2048) so every rank sees the whole image for image-space losses
@@ -132,10 +132,12 @@ class ShardedTracer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # build the LBVH for this rank's rays only (lrt_build_for_rays).  The library sizes the sort and the tree from the previous
-        # frame's kept count, so no read-back stalls the launch queue; a slab of a third of the sweep (120 degrees) is the widest
-        # whose ray cone culls anything (the cull keeps everything beyond ~80 degrees of half angle)
-        self.cull_build = self.world >= 3
+        # build the LBVH for this rank's rays only (lrt_build_for_rays): Gaussians outside the cone around the slab's rays are left
+        # out.  The library sizes the sort and the tree from the previous frame's kept count, so no read-back stalls the launch
+        # queue.  Measured on S1M (tools/slab_timing.py, profiles/r02_summary.md): the cull passes cost more than the smaller sort
+        # saves up to 4 ranks (N=4: build 0.27 -> 0.32 ms with a quarter of the Gaussians kept), and pay from 8 ranks on
+        # (0.27 -> 0.20-0.25 ms, an eighth kept); a 180-degree slab (N=2) has no useful cone at all.  Hence: on from 8 ranks.
+        self.cull_build = self.world >= 8
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
         if self.world > 1 and hasattr(self.backend, "defer_errors"):

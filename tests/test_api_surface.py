@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert set(_capi.EXPORTS) <= names
-    assert lib.lrt_abi_version() == 1
+    assert lib.lrt_abi_version() == 2
 
 
 def test_error_reporting_without_a_gpu(lib):

@@ -33,7 +33,7 @@ def test_two_ranks_on_one_gpu_match_single_rank():
 
 
 def test_three_ranks_with_ray_culled_builds_match_single_rank():
-    """The default from three ranks on (every rank builds the LBVH for its own slab's rays, sized speculatively from the previous frame)
+    """The default from eight ranks on (every rank builds the LBVH for its own slab's rays, sized speculatively from the previous frame)
     end to end through ShardedTracer, forced on at three ranks."""
     a, b = _bench(1), _bench(3, LRT_CULL_BUILD="1")
     assert b["n_gpus"] == 3

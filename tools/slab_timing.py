@@ -34,3 +34,40 @@ for N in (1, 2, 4, 8):
         f = lambda k: tm[k][0] / max(tm[k][1], 1)
         kept = be.state.built_count(dev)
         print(f"N={N} rank {r}: cols {b - a:4d}  kept {kept:7d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms")
+
+# ---- local cost of the owner-based gradient exchange for one rank (owner map + listing / packing of the foreign rows), and how
+# many rows a rank would send: the network leg itself cannot be measured on one GPU
+import ctypes as C
+from lidar_rt_amd import _capi
+from lidar_rt_amd.parallel import ShardedTracer
+lib = _capi.load(); p = _capi.ptr
+for N in (2, 4, 8):
+    st = ShardedTracer.__new__(ShardedTracer); st.world = N; st.rank = 0
+    st._rays_full = (torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev))
+    a, b = column_slab(W, 0, N)
+    o = torch.as_tensor(ro[:, a:b].copy(), device=dev); d = torch.as_tensor(rd[:, a:b].copy(), device=dev)
+    be.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+    out, acc = be.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+    be.backward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, out, dL[:, a:b].contiguous(), grads_out=grads)
+    lay.views["accum"].copy_(acc)
+    origin, axes = st.slab_axes()
+    owner = torch.empty(1000000, dtype=torch.int32, device=dev)
+    cap = 8192
+    cnt = torch.zeros(N, dtype=torch.int32, device=dev); idx = torch.empty((N, cap), dtype=torch.int32, device=dev)
+    rows = torch.empty((N, cap, lay.width), dtype=torch.float32, device=dev)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        e0.record()
+        lib.lrt_owner_by_direction(0, 1000000, p(t["means"]), p(origin), N, p(axes), p(owner), s)
+        e1.record()
+        v = lay.views
+        lib.lrt_grad_pack_foreign(0, 1000000, 16, N, 0, cap, p(owner), p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]),
+                                  p(v["accum"]), p(idx), p(cnt), p(rows), s)
+        e2.record()
+    torch.cuda.synchronize()
+    touched = int((acc > 0).sum()); own = int(((acc > 0) & (owner == 0)).sum())
+    print(f"N={N} rank 0 owner exchange: owner map {e0.elapsed_time(e1) * 1e3:.0f} us, list + pack {e1.elapsed_time(e2) * 1e3:.0f} us; touched {touched}, "
+          f"of which owned by the rank itself {own} ({100.0 * own / max(touched, 1):.1f} %), rows sent {cnt.tolist()} = {int(cnt.sum()) * lay.width * 4 / 1e6:.1f} MB "
+          f"(a replicating exchange would gather {touched * lay.width * 4 / 1e6:.1f} MB from every rank)")

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -48,7 +48,7 @@ except Exception:
     pass
 
 traffic = {}
-lines = [f"# rocprofv3 summary `{tag}` (MI355X, `python bench.py --steps 20 --warmup 3 --no-cpu-baseline`)\n",
+lines = [f"# rocprofv3 summary `{tag}` (MI355X, `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --min-seconds 0`)\n",
          "Raw rocprofv3 outputs were written under `gpurun_out/prof_%s/` on the GPU box; this file is the committed digest.\n" % tag]
 if bench:
     lines.append(f"bench line under `--kernel-trace --stats`: **{bench['value']/1e6:.2f} M rays/s**, {bench['ms_per_step']:.3f} ms/step; "
