@@ -82,7 +82,7 @@ def load():
     lib.lrt_knn_mean_dist2.restype = ci; lib.lrt_knn_mean_dist2.argtypes = [vp, ci, vp, vp, vp]
     lib.lrt_preprocess_forward.restype = ci; lib.lrt_preprocess_forward.argtypes = [ci, ci, ci] + [vp] * 11
     lib.lrt_preprocess_backward.restype = ci; lib.lrt_preprocess_backward.argtypes = [ci, ci, ci] + [vp] * 14
-    if lib.lrt_abi_version() != 1:
+    if lib.lrt_abi_version() != 2:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
     _lib = lib
     return lib
