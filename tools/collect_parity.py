@@ -18,3 +18,22 @@ for r in reps:
         print(f"| {k} | {v['max_rel']:.2e} | {v['p99_rel']:.2e} | {v['frac_gt_tol']:.2e} | {v['rel_l2']:.2e} | "
               f"{fl.get('frac_gt_tol', float('nan')):.2e} | {fl.get('rel_l2', float('nan')):.2e} | "
               f"{v.get('vs_f64', {}).get('frac_gt_tol', float('nan')):.2e} | {v.get('vs_f64', {}).get('rel_l2', float('nan')):.2e} |")
+
+
+# digest: per scene the worst output channel and the worst gradient (by fraction beyond the tolerance), floor beside it
+def _worst(rows, prefix):
+    best = None
+    for k, v in rows.items():
+        if k.startswith(prefix) and (best is None or v["frac_gt_tol"] > best[1]["frac_gt_tol"]): best = (k, v)
+    return best
+def _fmt(b):
+    if not b: return "-"
+    k, v = b; fl = v.get("floor", {})
+    return (f"{k.split('.', 1)[1]}: frac {v['frac_gt_tol']:.1e} (floor {fl.get('frac_gt_tol', float('nan')):.1e}), "
+            f"L2 {v['rel_l2']:.1e} (floor {fl.get('rel_l2', float('nan')):.1e}), p99 {v['p99_rel']:.1e}")
+md = ["| scene | rays | Gaussians | worst output channel (tol 1e-4) | worst gradient (tol 1e-3) | bound |", "|---|---|---:|---|---|---|"]
+for r in reps:
+    md.append(f"| {r['name']} | {'x'.join(map(str, r['rays']))} | {r['gaussians']} | {_fmt(_worst(r['rows'], 'out'))} | {_fmt(_worst(r['rows'], 'grad'))} | "
+              + (f"asserted: frac <= {r['k_frac']:g} x floor, L2 <= {r['k_l2']:g} x floor" if r["asserted"] else "recorded, not asserted against the floor") + " |")
+open(os.path.join(REPO, "profiles", f"{tag}_parity.md"), "w").write(
+    f"# Parity digest `{tag}` (HIP path against the fp32 oracle; floor = fp32 oracle against fp64 oracle; full table: {tag}_parity.json)\n\n" + "\n".join(md) + "\n")
