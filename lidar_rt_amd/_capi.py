@@ -7,7 +7,7 @@ loudly.  torch is used for device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
-import os
+import os, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
@@ -84,8 +84,24 @@ def load():
     lib.lrt_preprocess_backward.restype = ci; lib.lrt_preprocess_backward.argtypes = [ci, ci, ci] + [vp] * 14
     if lib.lrt_abi_version() != 2:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
+    if os.environ.get("LRT_TRACE_CALLS"):                    # developer aid: name every entry point on stderr and wait for the device after it
+        lib = _TraceCalls(lib)
     _lib = lib
     return lib
+
+
+class _TraceCalls:
+    def __init__(self, lib): self._lib = lib
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        if not callable(f) or name in ("lrt_last_error", "lrt_abi_version"): return f
+        def g(*a):
+            sys.stderr.write(f"[lrt] {name}\n"); sys.stderr.flush()
+            r = f(*a)
+            import torch
+            if torch.cuda.is_available(): torch.cuda.synchronize()
+            return r
+        return g
 
 
 def check(rc: int, what: str):

@@ -124,6 +124,16 @@ def test_checkpoint_tuple_layout_roundtrip():
 def test_ssim_and_range_frames():
     x = torch.rand(1, 24, 40)
     assert float(training.ssim(x, x)) == pytest.approx(1.0, abs=1e-6)
+    # the separable matrix form equals the reference's 2-D convolution with the outer-product window (loss_utils.py:45-89)
+    import torch.nn.functional as F
+    y = torch.rand_like(x)
+    g = torch.exp(-(torch.arange(11, dtype=torch.float32) - 5) ** 2 / (2 * 1.5 ** 2)); g = g / g.sum()
+    win = (g[:, None] @ g[None, :]).expand(x.shape[0], 1, 11, 11).contiguous()
+    conv = lambda a: F.conv2d(a, win, padding=5, groups=x.shape[0])
+    mu1, mu2 = conv(x), conv(y)
+    s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+    ref = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    assert float(training.ssim(x, y)) == pytest.approx(float(ref), abs=2e-6)
     assert float(training.ssim(x, 1 - x)) < 0.5
     fr = training.RangeFrames()
     o = torch.zeros(2, 3, 3); d = torch.nn.functional.normalize(torch.rand(2, 3, 3), dim=-1)
