@@ -55,6 +55,8 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     LRT_FAIL(LRT_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
+#include "lrt_radix.inc"
+
 struct lrt_state {
     int device;
     int P;               // primitives in the current BVH (-1: none)
@@ -78,6 +80,7 @@ struct lrt_state {
     unsigned long long* stats;   // 8 counters
     int stats_enabled;
     int tile_w_log2;
+    RsSorter sort_build, sort_bwd; int own_sort;     // radix sorts: 2 (default) = own onesweep (lrt_radix.inc) for builds of >= 131072 primitives and for backward sorts below 1 M keys; 1 = own for both; 0 = rocPRIM
     int n_nodes, n_leaves;
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
@@ -474,7 +477,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 24.0f; st->root_nodes = 8;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 24.0f; st->own_sort = 2; st->root_nodes = 8;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -508,7 +511,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); rs_free(st->sort_build); rs_free(st->sort_bwd);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
     delete st;
@@ -542,6 +545,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
     if (!strcmp(name, "fwd_mode")) { if (value != 0 && value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 (K-buffer packets) or 2 (collect & resolve, default); mode 1 was retired"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "root_nodes")) { if (value < 1 || value > 64) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: root_nodes must be in 1..64"); st->root_nodes = value; return LRT_OK; }
+    if (!strcmp(name, "own_sort")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: own_sort must be 0 (rocPRIM), 1 (own radix sort) or 2 (own for the build and for small backward sorts)"); st->own_sort = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
     if (!strcmp(name, "defer_errors")) { st->defer_errors = value ? 1 : 0; return LRT_OK; }   // 1: lrt_forward / lrt_backward do not report an overflow themselves (a sharded caller collects every rank's status and raises on all ranks alike); lrt_check_forward still does
     if (!strcmp(name, "spec_margin")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: spec_margin must be >= 0"); st->spec_margin = value; return LRT_OK; }   // hits added to the speculated size (tests set 0)
@@ -869,6 +873,14 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
             int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
+            if (st->own_sort == 1 || (st->own_sort == 2 && Pk >= LRT_BUILD_MERGE_LIMIT)) {      // below the limit rocPRIM's merge sort needs fewer launches
+                // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
+                int sb = pbits + 4; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
+                HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
+                uint64_t* kr = nullptr; uint32_t* vr = nullptr;
+                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr)));
+                if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
+            } else
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
             hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack, (const unsigned*)(spec ? cone + 10 : nullptr));
         }
@@ -1203,8 +1215,17 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     size_t tmpb = st->bsort_tmp_bytes;
                     // only the Gaussian bits are sorted: the sort is stable and the ids ascend in the input, so the order inside a run
                     // is the same as a full-key sort would give (3 instead of 6 radix passes)
+                    if (st->own_sort == 1 || (st->own_sort == 2 && n_hits < (1u << 20))) {      // large sorts: rocPRIM's pass is faster (38 vs 47 us at 4 M keys), small ones are launch bound
+                        HIPCHK(rs_reserve(st->sort_bwd, st->key_cap, 8, stream));
+                        unsigned long long* kr = nullptr;
+                        HIPCHK((rs_sort<unsigned long long, false, 8>(st->sort_bwd, st->hit_keys, st->hit_keys_sorted, nullptr, nullptr, n_hits, id_bits, id_bits + gbits, stream, &kr, nullptr)));
+                        tp.sorted_keys = kr;
+                        if (kr != st->hit_keys_sorted) { unsigned long long* t_ = st->hit_keys; st->hit_keys = st->hit_keys_sorted; st->hit_keys_sorted = t_; }
+                    } else {
                     HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(st->bsort_tmp, tmpb, st->hit_keys, st->hit_keys_sorted, (size_t)n_hits, LRT_BSORT_LO(id_bits), id_bits + gbits, stream));
-                    tp.sorted_keys = st->hit_keys_sorted; tp.n_hits = n_hits;
+                    tp.sorted_keys = st->hit_keys_sorted;
+                    }
+                    tp.n_hits = n_hits;
                     hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                 }
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise)

@@ -26,7 +26,8 @@ if torch.cuda.is_available():
 MODES = [{"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "bwd_mode": 1, "defer_colour": 0},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 0, "defer_colour": 1}]
+         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 0, "defer_colour": 1},
+         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 1}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 0}]
 GRADS = ("means", "scales", "rotations", "opacities", "shs")
 
 
@@ -46,7 +47,7 @@ def s10k():
     return sc, o, d, dL
 
 
-@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else ""))
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else "") + (f"-sort{m['own_sort']}" if "own_sort" in m else ""))
 @pytest.mark.parametrize("deg,bg", [(3, (0, 0, 1)), (0, (0, 0, 0)), (1, (0.3, 0.7, 0.2)), (2, (0, 0, 1))])
 def test_s10k_forward_backward_match_oracle(s10k, mode, deg, bg):
     sc, o, d, dL = s10k
@@ -203,6 +204,21 @@ def test_forward_modes_agree_and_backward_is_deterministic(s10k):
         assert (a["grads"][k] != c["grads"][k]).mean() < 1e-3
     e = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "defer_colour": 0})     # colour in the trace kernel: other summation order
     assert rel_l2(e["out"], a["out"]) < 1e-6
+
+
+def test_own_radix_sort_and_rocprim_give_the_same_results():
+    """lrt_radix.inc (own onesweep: epoch-tagged look-back words, ticket counter, no fills) against rocPRIM for both sorts of a step,
+    on sizes with one tile, a few tiles and hundreds of tiles per pass; twice in a row (epochs / tickets carry over)."""
+    for P, (H, W) in ((3_000, (8, 64)), (40_000, (16, 256)), (300_000, (32, 512))):
+        sc = scenes.make_scene(P, radius_scale=0.5 if P > 100_000 else 0.25)
+        o, d = scenes.kitti_rays(H, W)
+        dL = scenes.upstream_grad(H, W)
+        ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"own_sort": 0})
+        for rep in range(2):
+            got = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"own_sort": 1})
+            np.testing.assert_array_equal(got["out"], ref["out"])              # the image does not depend on the order inside a Morton cell
+            for k in GRADS:                                                    # both sorts are stable: same runs, same summation order
+                assert rel_l2(got["grads"][k], ref["grads"][k]) < 1e-7, (P, k)
 
 
 # ---------------------------------------------------------------------------------- larger scenes, statistical parity
