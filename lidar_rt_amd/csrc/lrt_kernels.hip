@@ -64,7 +64,6 @@ struct lrt_state {
     // grow-only workspace
     size_t capP;
     float* rec;          // capP * 16   sorted splat records
-    float* rec_il;       // the same records, leaf by leaf in the pair-interleaved image k_fwd_cr6 reads (lrt_store_interleaved)
     float* aabb;         // capP * 6    sorted quad AABBs (build only)
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
@@ -362,8 +361,6 @@ __global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restri
 
 #include "lrt_collect.inc"
 #include "lrt_collect4.inc"
-#include "lrt_collect5.inc"
-#include "lrt_collect6.inc"
 #include "lrt_near.inc"
 
 __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
@@ -418,13 +415,12 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->rec_il, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack};
     for (void* q : olds) (void)hipFree(q);
-    st->nodes_aos = nullptr; st->pack = nullptr; st->rec_il = nullptr;
+    st->nodes_aos = nullptr; st->pack = nullptr;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
-    HIPCHK(hipMalloc(&st->rec_il, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc(&st->aabb, cap * 6 * sizeof(float)));
     HIPCHK(hipMalloc(&st->pack, cap * 4 * sizeof(float4)));
     HIPCHK(hipMalloc(&st->keys_a, cap * sizeof(uint64_t)));
@@ -509,7 +505,7 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->rec_il, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
     if (st->cone_host) { (void)hipHostFree(st->cone_host); (void)hipEventDestroy(st->cone_ev); }
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -547,7 +543,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     }
     if (!strcmp(name, "hit_cap_auto")) { st->hit_cap_auto = value ? 1 : 0; return LRT_OK; }   // 1 (default): the record capacity doubles after an overflow
     if (!strcmp(name, "replay")) { st->replay_enabled = value ? 1 : 0; return LRT_OK; }   // 0: backward always re-traces
-    if (!strcmp(name, "fwd_mode")) { if (value != 0 && value != 2 && value != 3 && value != 4) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 (K-buffer packets), 2 (collect & resolve in workgroup rounds), 3 (barrier-free collection) or 4 (barrier-free collection fed by LDS-DMA); mode 1 was retired"); st->fwd_mode = value; return LRT_OK; }
+    if (!strcmp(name, "fwd_mode")) { if (value != 0 && value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fwd_mode must be 0 (K-buffer packets) or 2 (collect & resolve, default); mode 1 was retired"); st->fwd_mode = value; return LRT_OK; }
     if (!strcmp(name, "root_nodes")) { if (value < 1 || value > 64) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: root_nodes must be in 1..64"); st->root_nodes = value; return LRT_OK; }
     if (!strcmp(name, "own_sort")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: own_sort must be 0 (rocPRIM), 1 (own radix sort) or 2 (own for the build and for small backward sorts)"); st->own_sort = value; return LRT_OK; }
     if (!strcmp(name, "c4_queue_limit")) { if (value < 136 || value > C4_NQ) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_queue_limit must be 136..%d", C4_NQ); st->c4_qlimit = value; return LRT_OK; }
@@ -886,7 +882,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
             } else
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
-            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack, (const unsigned*)(spec ? cone + 10 : nullptr), st->rec_il);
+            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack, (const unsigned*)(spec ? cone + 10 : nullptr));
         }
     }
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
@@ -921,7 +917,7 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
     float4* pack = st->no_pack ? nullptr : st->pack;
     if (pack) hipLaunchKernelGGL(k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack);
     hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod,
-                       st->rec, st->aabb, (const float4*)pack, (const unsigned*)nullptr, st->rec_il);
+                       st->rec, st->aabb, (const float4*)pack, (const unsigned*)nullptr);
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
     tree_layout(P, &nl, &L, cnt, off);
     hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
@@ -1008,7 +1004,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         st->near_cap = HW;
     }
     tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
-    const bool defer = st->fwd_mode >= 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
+    const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc || st->key_avg > st->key_avg_alloc) {
@@ -1045,7 +1041,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
     }
     // k_fwd_cr4 addresses the leaf records with 32-bit byte offsets: beyond 2^26 primitives the K-buffer packet kernel takes over
-    if (st->fwd_mode >= 2 && (size_t)P < ((size_t)1 << 26)) {
+    if (st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26)) {
         const bool wg4 = true;                                      // one workgroup of 4 (or 8) waves per 16-ray tile: k_fwd_cr4
         const int tile_rays = C4_RAYS;
         const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
@@ -1103,22 +1099,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             ScopedTimer tm(st, 1, stream);
             const float* rec_ = (const float*)st->rec; const float* naos_ = (const float*)st->nodes_aos;
             const bool dfr = defer && record;
-            if (st->fwd_mode == 4) {                              // barrier-free collection, node / leaf batches by LDS-DMA (leaves from the interleaved image)
-                const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
-                const dim3 g_(blocks), b_(64 * nw);
-                const float* il_ = (const float*)st->rec_il;
-#define LRT_CR6(D_, N_, S_) hipLaunchKernelGGL((k_fwd_cr6<D_, N_, S_>), g_, b_, 0, stream, tp, il_, naos_)
-                if (nw == 8) { if (dfr) { if (sts) LRT_CR6(true, 8, true); else LRT_CR6(true, 8, false); } else { if (sts) LRT_CR6(false, 8, true); else LRT_CR6(false, 8, false); } }
-                else         { if (dfr) { if (sts) LRT_CR6(true, 4, true); else LRT_CR6(true, 4, false); } else { if (sts) LRT_CR6(false, 4, true); else LRT_CR6(false, 4, false); } }
-#undef LRT_CR6
-            } else if (st->fwd_mode == 3) {                              // barrier-free collection; the STATS instantiations only when counters are asked for
-                const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
-                const dim3 g_(blocks), b_(64 * nw);
-#define LRT_CR5(D_, N_, S_) hipLaunchKernelGGL((k_fwd_cr5<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
-                if (nw == 8) { if (dfr) { if (sts) LRT_CR5(true, 8, true); else LRT_CR5(true, 8, false); } else { if (sts) LRT_CR5(false, 8, true); else LRT_CR5(false, 8, false); } }
-                else         { if (dfr) { if (sts) LRT_CR5(true, 4, true); else LRT_CR5(true, 4, false); } else { if (sts) LRT_CR5(false, 4, true); else LRT_CR5(false, 4, false); } }
-#undef LRT_CR5
-            } else if (wg4 && nw == 8) {
+            if (wg4 && nw == 8) {
                 if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
                 else hipLaunchKernelGGL((k_fwd_cr4<false, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
             } else {

@@ -43,9 +43,6 @@ if os.environ.get("C4_PROF"):
     pr = raw[8 * NT: 8 * NT + 16 * NT].reshape(NT, 16)[:, :10]
     names = ["first select+commit", "select_issue(next)", "process leaves", "process nodes", "round barrier", "push counters + late select", "commit (vmcnt wait + LDS stores)",
              "phase A tail (waitcnt, barrier, overflow test)", "slab prologue (barriers, flags)", "phase B"]
-    if "fwd_mode=4" in os.environ.get("LRT_OPTS", ""):     # k_fwd_cr6's marks
-        names = ["-", "fill (queue reads, DMA issue)", "process leaves", "process nodes", "idle: wait for a donation / take it", "pop, overflow test, donation",
-                 "wait for the oldest batch (vmcnt)", "phase A tail (all idle -> waitcnt, barrier, overflow test)", "slab prologue (barriers, flags, roots)", "phase B"]
     tot = pr.sum()
     print("wave-0 cycles per tile by segment (mean; share):")
     for k, n in enumerate(names):
