@@ -120,10 +120,12 @@ def main():
     ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. fwd_mode=0, bwd_mode=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="owner", choices=["owner", "dense", "sparse", "auto"], help="gradient exchange for N > 1: owner = every "
-                    "Gaussian's gradient is reduced to its owning rank (one padded all_to_all of the touched rows, reduce-scatter semantics); "
-                    "dense = all_reduce of the flat buffer (replicated); sparse / auto = all_gather of the touched rows (replicated)")
-    ap.add_argument("--min-seconds", type=float, default=2.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
+    ap.add_argument("--exchange", default="sparse", choices=["owner", "dense", "sparse", "auto"], help="gradient exchange for N > 1: sparse (default) = "
+                    "all_gather of the touched Gaussians' rows, every rank ends with the full gradient (what a replicated optimizer -- the sharded "
+                    "training step -- consumes; nothing else has to be synchronised); dense = all_reduce of the flat buffer (replicated); owner = "
+                    "every Gaussian's gradient is reduced to its owning rank only (reduce-scatter semantics: NOT a complete training exchange, "
+                    "parameters and Adam moments of the touched rows would still have to be synchronised)")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
                     "at least this long (one window, bracketed once; `steps` in the output is what ran, `steps_requested` what was asked); 0 = exactly --steps")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
@@ -295,7 +297,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
                        "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
-                               + (" + slab all_gather + gradient exchange (RCCL: all_gather of the touched Gaussians' rows, or one fused all_reduce)" if world > 1 else ""),
+                               + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (counts verified inside the step: one small device->host read)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange},
             "roofline": roof,

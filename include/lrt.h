@@ -160,7 +160,11 @@ int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, co
  *   lrt_grad_pack_foreign         cnt[N] (zeroed here; keeps counting beyond cap), idx (N, cap), rows (N, cap, 11 + 3M) of the Gaussians
  *                                 this rank touched (accum > 0) and does not own; row layout of lrt_grad_gather
  *   lrt_grad_scatter_add_counted  add one received list (count on the device, at most cap rows) into the dense tensors
- *   lrt_status_to_device          this state's error bits (last forward | sticky) as one float at a device address */
+ *   lrt_status_to_device          this state's error bits (last forward | sticky) as one float at a device address
+ * Gathering (replicated) exchange: every rank sends the rows of ALL Gaussians it touched to every rank (one all-gather) and all
+ * ranks add the lists in rank order, so that the replicas end with bit-identical sums.
+ *   lrt_grad_pack_touched         cnt[1] (zeroed here; keeps counting beyond cap), idx (cap), rows (cap, 11 + 3M) of the touched Gaussians
+ *   lrt_grad_zero_rows_counted    zero the rows of one list in the dense tensors (a rank clears what it wrote itself before the adds) */
 int lrt_owner_by_direction(int device, int P, const float* means, const float* origin, int N, const float* axes, int32_t* owner, void* stream);
 int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, const int32_t* owner, const float* d_means, const float* d_scales,
                           const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx,
@@ -168,6 +172,10 @@ int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, co
 int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, const float* rows, float* d_means,
                                  float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
 int lrt_status_to_device(lrt_state* st, float* dst, void* stream);
+int lrt_grad_pack_touched(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations,
+                          const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx, unsigned* cnt, float* rows, void* stream);
+int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, float* d_means, float* d_scales,
+                               float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -307,8 +307,9 @@ __global__ void __launch_bounds__(256) k_grad_rows(int n, int width, const int32
     if (GATHER) rows[t] = *p; else *p += rows[t];
 }
 
-// Counted variants for the owner-based exchange: list l of `nlists` holds cnt[l] (device) rows of at most `cap`; thread = (list, row, column).
-template <bool GATHER>
+// Counted variants for the owner-based and the gathering exchange: list l of `nlists` holds cnt[l] (device) rows of at most `cap`;
+// thread = (list, row, column).  MODE 0: rows <- dense, 1: dense += rows, 2: dense rows <- 0.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_grad_rows_multi(int cap, int width, const unsigned* __restrict__ cnt, const int32_t* __restrict__ idx,
                                                          GradFields g, float* rows, int skip_list)
 {
@@ -323,8 +324,24 @@ __global__ void __launch_bounds__(256) k_grad_rows_multi(int cap, int width, con
     int k = 0;
     while (e >= g.w[k]) { e -= g.w[k]; k++; }
     float* p = g.f[k] + (size_t)gi * g.w[k] + e;
+    if (MODE == 2) { *p = 0.f; return; }
     float* q = rows + ((size_t)l * cap + r) * width + (t - (long long)r * width);
-    if (GATHER) *q = *p; else *p += *q;
+    if (MODE == 0) *q = *p; else *p += *q;
+}
+
+// Gaussians this rank touched (accum > 0), in index order inside a block and block order by the counter: at most cap are listed,
+// cnt keeps counting beyond cap so that the overflow is visible
+__global__ void __launch_bounds__(256) k_list_touched(int P, int cap, const float* __restrict__ accum, int32_t* __restrict__ idx, unsigned* __restrict__ cnt)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool t = g < P && accum[g] > 0.f;
+    const unsigned long long m = __ballot(t);
+    if (!m) return;
+    unsigned base = 0u;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(cnt, (unsigned)__popcll(m));     // one atomic per wave
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned slot = base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    if (t && slot < (unsigned)cap) idx[slot] = g;
 }
 
 // owner[g] = the rank whose slab axis is closest to the direction sensor -> Gaussian (ties: the lowest rank)
@@ -690,7 +707,7 @@ int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, co
     g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
     const int width = 11 + 3 * M;
     const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<true>, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, rank);
+    hipLaunchKernelGGL(k_grad_rows_multi<0>, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, rank);
     HIPCHK(hipGetLastError());
     return LRT_OK;
 }
@@ -706,7 +723,44 @@ int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsign
     g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
     const int width = 11 + 3 * M;
     const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<false>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, const_cast<float*>(rows), -1);
+    hipLaunchKernelGGL(k_grad_rows_multi<1>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, const_cast<float*>(rows), -1);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+/* Gathering (replicated) exchange, sender side: list the Gaussians this rank touched (accum > 0; cnt[0] zeroed here, keeps counting
+ * beyond cap) and pack their rows (cap, 11 + 3M) -- the row layout of lrt_grad_gather. */
+int lrt_grad_pack_touched(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations,
+                          const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx, unsigned* cnt, float* rows, void* stream_)
+{
+    if (P < 0 || M < 0 || cap < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_touched: bad sizes");
+    if (!idx || !cnt || !rows || (P > 0 && !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_touched: null pointer");
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_pack_touched: cannot select HIP device %d", device);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned), stream));
+    if (P == 0) return LRT_OK;
+    hipLaunchKernelGGL(k_list_touched, dim3((P + 255) / 256), dim3(256), 0, stream, P, cap, accum, idx, cnt);
+    GradFields g; g.f[0] = const_cast<float*>(d_means); g.w[0] = 3; g.f[1] = const_cast<float*>(d_scales); g.w[1] = 2; g.f[2] = const_cast<float*>(d_rotations); g.w[2] = 4;
+    g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
+    const int width = 11 + 3 * M;
+    const long long per = (long long)cap * width;
+    hipLaunchKernelGGL(k_grad_rows_multi<0>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, -1);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+/* Zero the rows of ONE list (count on the device) in the dense tensors: the gathering exchange clears exactly what this rank wrote
+ * before it adds every rank's rows in rank order (the rest of the buffers is zero already). */
+int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, float* d_means, float* d_scales,
+                               float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream_)
+{
+    if (P < 0 || M < 0 || cap < 1 || !cnt_dev || !idx) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_zero_rows_counted: bad argument");
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_zero_rows_counted: cannot select HIP device %d", device);
+    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rotations; g.w[2] = 4; g.f[3] = d_opacities; g.w[3] = 1;
+    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
+    const int width = 11 + 3 * M;
+    const long long per = (long long)cap * width;
+    hipLaunchKernelGGL(k_grad_rows_multi<2>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, (float*)nullptr, -1);
     HIPCHK(hipGetLastError());
     return LRT_OK;
 }

@@ -3,8 +3,8 @@
 * ``render_frames``  -- ``Evaluator.record_render`` (eval.py:100-124): forward-only per-frame rendering through
   ``renderer.raytracing``.  The reference's tracer ends every call in ``cudaStreamSynchronize`` (DLT/trace_surfels.cpp:260); here
   the frames are ENQUEUED back to back (``Tracer.deferred_checks``), the overflow status of all of them is checked once at the end.
-* the metric set of eval.py:282-365 on device tensors: depth / intensity (rmse, mae, medae, ssim, psnr), ray-drop (rmse, accuracy,
-  F1 at ``raydrop_ratio``), points (Chamfer distance and F-score at 5 cm through the package's own ``chamfer_3DDist``).
+* the metric set of eval.py:282-365 on device tensors: depth / intensity (rmse, mae, medae, ssim = skimage's 7x7 uniform-window
+  structural_similarity with the ground truth's data range, psnr), ray-drop (rmse, accuracy, F1 at ``raydrop_ratio`` = 0.4), points (Chamfer distance and F-score at 5 cm through the package's own ``chamfer_3DDist``).
   Not reproduced: LPIPS (needs pretrained network weights), the U-Net ray-drop refinement, image / point-cloud dumps.
 * ``evaluate``       -- the loop of eval.py:370-470: per-frame metrics and their means.
 
@@ -18,7 +18,6 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import torch
 
 from . import renderer
-from .training import ssim
 
 
 def render_frames(gaussian_assets: Sequence, sensor, frame_ids: Iterable, background: torch.Tensor, args=None,
@@ -47,13 +46,37 @@ def render_frames(gaussian_assets: Sequence, sensor, frame_ids: Iterable, backgr
 
 
 # ---------------------------------------------------------------------------------------------------------------- metrics
+def ssim_uniform(pred: torch.Tensor, gt: torch.Tensor, data_range: torch.Tensor, win: int = 7) -> torch.Tensor:
+    """`skimage.metrics.structural_similarity(pred, gt, data_range=...)` with its defaults, which is what eval.py:299-301 / :323-325
+    calls: 7x7 UNIFORM window, K1 = 0.01, K2 = 0.03, sample covariance (normalised by N / (N - 1)), mean over the image with a
+    border of (win - 1) / 2 pixels cropped -- on that interior the uniform filter equals an un-padded average pooling."""
+    import torch.nn.functional as F
+    x = pred.reshape(1, 1, *pred.shape[-2:]).double(); y = gt.reshape(1, 1, *gt.shape[-2:]).double()
+    pool = lambda a: F.avg_pool2d(a, win, stride=1)
+    ux, uy = pool(x), pool(y)
+    norm = win * win / (win * win - 1.0)
+    vx = norm * (pool(x * x) - ux * ux); vy = norm * (pool(y * y) - uy * uy); vxy = norm * (pool(x * y) - ux * uy)
+    R = data_range.double()
+    C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
+    return S.mean().float()
+
+
+def _median(x: torch.Tensor) -> torch.Tensor:
+    """numpy's median: the mean of the two middle elements for an even count (torch.median returns the lower one)."""
+    v = x.flatten().sort().values
+    n = v.numel()
+    return 0.5 * (v[(n - 1) // 2] + v[n // 2])
+
+
 def _image_metrics(gt: torch.Tensor, pred: torch.Tensor, lo: float, hi: float) -> Dict[str, torch.Tensor]:
-    """eval.py:282-331: clamp both to [lo, hi]; rmse, mae, medae, ssim (11x11 Gaussian window), psnr with peak `hi`."""
+    """eval.py:282-331: clamp both to [lo, hi]; rmse, mae, medae, ssim (skimage defaults, data range of the clamped ground truth),
+    psnr with peak `hi`.  LPIPS is not reproduced (pretrained network weights)."""
     gt = gt.reshape(gt.shape[0], gt.shape[1]).clamp(lo, hi).float(); pred = pred.reshape(gt.shape).clamp(lo, hi).float()
     err = gt - pred
     mse = (err * err).mean()
-    return {"rmse": mse.sqrt(), "mae": err.abs().mean(), "medae": err.abs().flatten().median(),
-            "ssim": ssim(pred.unsqueeze(0), gt.unsqueeze(0)), "psnr": 10.0 * torch.log10(hi * hi / mse.clamp_min(1e-30))}
+    return {"rmse": mse.sqrt(), "mae": err.abs().mean(), "medae": _median(err.abs()),
+            "ssim": ssim_uniform(pred, gt, gt.max() - gt.min()), "psnr": 10.0 * torch.log10(hi * hi / mse.clamp_min(1e-30))}
 
 
 def depth_metrics(gt, pred, min_depth: float = 1e-6, max_depth: float = 80.0):
@@ -87,9 +110,11 @@ def points_metrics(gt_pts: torch.Tensor, pred_pts: torch.Tensor, threshold: floa
 
 
 def evaluate(gaussian_assets: Sequence, sensor, frame_ids: Sequence, background: torch.Tensor, args=None,
-             raydrop_ratio: float = 0.5, use_gt_mask: bool = False, max_depth: float = 80.0) -> Dict[str, object]:
-    """Per-frame metrics and their means (eval.py:370-470).  `sensor` offers get_depth / get_intensity / get_mask /
-    inverse_projection_with_range like ``training.RangeFrames``.  One device->host transfer at the end."""
+             raydrop_ratio: float = 0.4, use_gt_mask: bool = False, max_depth: float = 80.0) -> Dict[str, object]:
+    """Per-frame metrics and their means (eval.py:370-470; `raydrop_ratio` 0.4 as eval.py:72).  `sensor` offers get_depth /
+    get_intensity / get_mask / inverse_projection_with_range like ``training.RangeFrames``.  As in ``record_render`` the rendered
+    depth and the clamped rendered intensity are multiplied by the ray-hit mask (ground-truth or predicted, eval.py:184, :224, :238)
+    before they are compared with the ground truth.  One device->host transfer at the end."""
     frame_ids = list(frame_ids)
     renders = render_frames(gaussian_assets, sensor, frame_ids, background, args)
     per_frame: Dict[object, Dict[str, Dict[str, torch.Tensor]]] = {}
@@ -100,8 +125,9 @@ def evaluate(gaussian_assets: Sequence, sensor, frame_ids: Sequence, background:
         mask = gt_hit if use_gt_mask else pred_hit
         gt_pts = sensor.inverse_projection_with_range(f, sensor.get_depth(f), gt_hit)
         pred_pts = sensor.inverse_projection_with_range(f, r["depth"].squeeze(-1), mask)
-        per_frame[f] = {"depth": depth_metrics(sensor.get_depth(f), r["depth"], max_depth=max_depth),
-                        "intensity": intensity_metrics(sensor.get_intensity(f).clamp(0, 1), r["intensity"]),
+        mk = mask.to(r["depth"].dtype)
+        per_frame[f] = {"depth": depth_metrics(sensor.get_depth(f), r["depth"].squeeze(-1) * mk, max_depth=max_depth),
+                        "intensity": intensity_metrics(sensor.get_intensity(f).clamp(0, 1), r["intensity"].squeeze(-1).clamp(0, 1.0) * mk),
                         "raydrop": raydrop_metrics(1 - gt_hit.float(), 1 - pred_hit.float()),
                         "points": points_metrics(gt_pts, pred_pts)}
     # one transfer: stack every scalar

@@ -13,20 +13,25 @@ cone can reach (``lrt_build_for_rays``; below that the cull costs more than it s
 * backward: each rank's partial gradients live in ONE flat fp32 buffer
   ``[d_means | d_scales | d_rotations | d_opacities | d_shs | accum]``
   (59 + 1 floats per Gaussian at M=16).  Three exchanges:
-    - ``owner``  (what bench.py uses for N > 1): every Gaussian has ONE owning rank -- the rank whose slab axis is closest to the
-      direction sensor -> Gaussian -- and a rank's rows of touched Gaussians travel to their owner only: one padded
-      ``all_to_all`` with a fixed, speculated capacity per (source, owner) pair; no ``nonzero`` / ``tolist`` round trips.
-      Azimuth sectors touch mostly their own Gaussians, so a rank sends a few per cent of what it touched.  Result: the
-      gradient of Gaussian g is COMPLETE on ``owner[g]`` and meaningless elsewhere (``last_owner`` holds the map) -- the
-      shape a sector-sharded optimizer wants (reduce-scatter semantics).
-    - ``dense``  : one ``all_reduce`` of the flat buffer (replicated result; a single large message so that RCCL can use
-      all 7 xGMI links).
-    - ``sparse`` : replicated result through an ``all_gather`` of the touched rows (two small host round trips for the row
-      counts: kept for replicated optimizers, not used by the bench).
+    - ``sparse`` (what bench.py and the sharded training step use): REPLICATED result.  Every rank packs the rows of the Gaussians
+      it touched (``accum > 0``: list + pack on the device, fixed speculated capacity, no ``nonzero`` / ``tolist``) and ONE
+      ``all_gather`` of ``[count | indices | rows]`` moves them to everybody; a rank then clears the rows it wrote itself and adds
+      every rank's list in rank order, so all replicas hold bit-identical sums -- what a replicated optimizer (and the replicated
+      densification decisions of the training loop) needs: parameters never diverge and no parameter synchronisation exists.
+    - ``dense``  : one ``all_reduce`` of the flat buffer (replicated; a single large message so that RCCL can use all 7 xGMI links).
+    - ``owner``  : reduce-scatter semantics.  Every Gaussian has ONE owning rank -- the rank whose slab axis is closest to the
+      direction sensor -> Gaussian -- and a rank's rows travel to their owner only: one padded ``all_to_all``.  The gradient of
+      Gaussian g is COMPLETE on ``owner[g]`` and meaningless elsewhere (``last_owner`` holds the map).  Azimuth sectors touch
+      mostly their own Gaussians, so a rank sends a few per cent of what it touched -- but a training loop on top of it has to
+      synchronise parameters AND Adam moments of the touched rows afterwards (3 x 59 floats per row against the 59 the gathering
+      exchange moves once), which is why the training step uses ``sparse``.
+  Capacities are speculated from the previous step; the true counts travel with the rows and are VERIFIED INSIDE THE STEP (one
+  small device->host read after the collective): an overflow re-runs the exchange with an exact capacity before anything is
+  added, on all ranks alike, so no step ever hands incomplete gradients to an optimizer.
 * errors: the kernels raise device-side flags; a rank that raised alone would leave the others blocked in the next
-  collective.  Every rank therefore sends its status word with its slab (and the exchange its overflow counts with the
-  rows), keeps what it received in pinned memory, and ALL ranks raise the same ``LrtError`` at their next call into
-  ``ShardedTracer`` (or ``check()``) -- one step late, consistently, without a host wait in the step itself.
+  collective.  Every rank therefore sends its status word with its slab, keeps what it received in pinned memory, and ALL ranks
+  raise the same ``LrtError`` at their next call into ``ShardedTracer`` (or ``check()``) -- one step late, consistently, without a
+  host wait in the forward itself.
 
 The local tracer is injected (``backend``): the product default drives the HIP
 library; the CPU tests inject an oracle-backed stand-in to exercise the
@@ -146,11 +151,11 @@ class ShardedTracer:
         self._phase_on = False
         self._phase_ev = []            # (name, start event, end event) of the collectives' regions, read back by phase_timing()
         self._pending = []             # [(what, pinned host tensor, event or None)] status words received from all ranks, not yet looked at
-        self._cap = None               # rows per (source, owner) pair of the owner exchange (speculated from earlier steps)
+        self._cap = None               # rows per message of the owner / gathering exchange (speculated from the previous step's counts)
         self._cap_key = None
-        self._worst_dev = None         # (1,) float32 on the device: largest row count of this rank's last owner exchange
-        self._worst_cap = 0            # ... and the capacity that exchange ran with
-        self._counts = []              # [(pinned (N,) counts of all ranks, event, capacity of that exchange)] not yet absorbed
+        self.exchange_reruns = 0       # exchanges that had to run again with an exact capacity (statistics / tests)
+        self.first_cap = None          # test hook: capacity of the first exchange of a size instead of the built-in guess
+        self._bufs = {}                # reused message buffers of the exchanges, keyed by (what, shape)
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True):
@@ -188,38 +193,9 @@ class ShardedTracer:
         else:
             self._pending.append((what, dev_values.clone(), None))
 
-    def _remember_counts(self, dev_counts: torch.Tensor, cap_used: int):
-        if dev_counts.is_cuda:
-            host = torch.empty(dev_counts.shape, dtype=dev_counts.dtype, pin_memory=True)
-            host.copy_(dev_counts, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-        else:
-            host, ev = dev_counts.clone(), None
-        self._counts.append((host, ev, cap_used))
-
-    def _absorb_counts(self):
-        """Row counts of earlier owner exchanges that have reached the host: the largest sizes the next exchange (the same data
-        and the same rule on every rank, so every rank arrives at the same capacity); a count beyond the capacity it ran with is an
-        overflow, reported by check() like the forward's."""
-        for host, ev, cap_used in self._counts:
-            if ev is not None:
-                ev.synchronize()                       # recorded a step ago; every rank absorbs the same set (never skip one: the
-                                                       # capacities of all ranks must stay equal)
-            biggest = int(host.max().item())
-            if cap_used and biggest > cap_used:
-                self._pending.append(("exchange", torch.tensor([float(biggest), float(cap_used)]), None))
-                self._cap = None
-            elif self._cap is not None:
-                want = biggest + biggest // 4 + 1024
-                if want > self._cap or want < self._cap // 2:
-                    self._cap = want
-        self._counts = []
-
     def check(self, wait: bool = True):
         """Raise on EVERY rank alike if any rank reported an overflow in a step whose status has arrived (wait=True: in all
         earlier steps).  Called at the start of forward()."""
-        if wait:
-            self._absorb_counts()
         still = []
         bad = None
         for what, host, ev in self._pending:
@@ -236,12 +212,9 @@ class ShardedTracer:
             if hasattr(self.backend, "clear_errors") and getattr(self, "_dev", None) is not None and self._dev.type == "cuda":
                 self.backend.clear_errors(self._dev)
             what, vals = bad
-            if what == "exchange":
-                self._cap = None                               # next exchange sizes itself from the true counts again
             raise LrtError(f"sharded tracer: a rank reported an overflow in an earlier step ({what}; per-rank words {vals}); that step's "
                            "results are incomplete on it.  forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
-                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly); exchange: "
-                           "rows beyond the speculated capacity (the next exchange is sized exactly)")
+                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly)")
 
     @staticmethod
     def _backend_takes(fn, name: str) -> bool:
@@ -282,8 +255,6 @@ class ShardedTracer:
             msg[2:].view(H, wmax, 9)[:, :b - a] = out_loc
             if hasattr(self.backend, "status_to") and out_loc.is_cuda:
                 self.backend.status_to(msg)                  # word 0: this rank's forward / build status bits
-            if self._worst_dev is not None:
-                msg[1:2] = self._worst_dev                   # word 1: the largest row count of this rank's previous owner exchange
             parts = self._all_gather_rows(msg)               # one flat receive buffer with RCCL
             cols = []
             for r in range(self.world):
@@ -292,8 +263,6 @@ class ShardedTracer:
             full = torch.cat(cols, dim=1)
             hdr = torch.stack([p[:2] for p in parts])        # (N, 2), identical on every rank
             self._remember("forward", hdr[:, 0])
-            if self._worst_dev is not None:
-                self._remember_counts(hdr[:, 1], self._worst_cap)
         return full, accum_loc                          # accum is completed by backward()'s exchange
 
     # ---- backward ---------------------------------------------------------------------------------------------------------------
@@ -388,130 +357,199 @@ class ShardedTracer:
             return owner
         return ((means.detach() - origin) @ axes.T).argmax(1).to(torch.int32)     # torch's argmax also returns the first maximum
 
+    # ---- helpers of the exchanges ------------------------------------------------------------------------------------------------
+    def _buf(self, what: str, shape, dtype, dev) -> torch.Tensor:
+        """A message buffer that lives across steps (no per-step allocation of the padded lists)."""
+        key = (what, tuple(shape), dtype, str(dev))
+        t = self._bufs.get(key)
+        if t is None:
+            for k in [k for k in self._bufs if k[0] == what]:
+                del self._bufs[k]
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=dev)
+        return t
+
+    @staticmethod
+    def _to_host(t: torch.Tensor) -> list:
+        """Values of a small device tensor: the ONE host wait of an exchange (the counts that verify its capacity)."""
+        if t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            return h.reshape(-1).tolist()
+        return t.reshape(-1).tolist()
+
+    def _start_cap(self, key, P: int, guess: int) -> int:
+        if self._cap_key != key:
+            self._cap, self._cap_key = None, key
+        if self._cap is None and self.first_cap is not None:
+            guess = int(self.first_cap)
+        return min(max(self._cap if self._cap is not None else guess, 1), max(P, 1))
+
+    def _adapt_cap(self, biggest: int):
+        want = biggest + biggest // 4 + 1024
+        if self._cap is None or want > self._cap or want < self._cap // 2:
+            self._cap = want
+
+    @staticmethod
+    def _row_fields(M: int):
+        return [(name, k) for name, k in GradLayout.FIELDS] + [("shs", 3 * M), ("accum", 1)]
+
     def _exchange_owner(self, lay: GradLayout, means: torch.Tensor):
         """Rows of touched Gaussians go to their owner: ONE all_to_all of ``N x [count | cap indices | cap rows]`` per rank.
         The capacity per (source, owner) pair is speculated from the previous exchange's largest count (x1.25 + 1024); the true
-        counts travel with the rows, land in pinned memory and size the next step; an overflow is reported by check()."""
+        counts travel with the rows; their maximum over all pairs is all-reduced and read by the host BEFORE anything is added: a
+        count beyond the capacity re-runs pack + all_to_all with an exact capacity, on all ranks alike."""
         P, M, N, rank = lay.P, lay.M, self.world, self.rank
         width = lay.width
         dev = lay.flat.device
         owner = self.owner_map(means)
         self.last_owner = owner
-        key = (P, M, N)
-        if self._cap_key != key:
-            self._cap, self._cap_key, self._counts, self._worst_dev = None, key, [], None
-        # NOTE: every rank must arrive at the same capacity: it only depends on data that all ranks share (the all-gathered counts)
-        # and on which of them have reached the host -- absorbed in forward(), right after check(), where all ranks wait alike
-        if self._cap is None:
-            # first exchange of this size (or after an overflow): the exact counts, one host wait
-            foreign = (lay.views["accum"] > 0) & (owner != rank)
-            mine = torch.bincount(owner[foreign].long(), minlength=N).max().reshape(1)
-            allc = torch.stack(self._all_gather_rows(mine)).max()
-            c = int(allc.item())
-            self._cap = c + c // 4 + 1024
-        cap = min(self._cap, max(P, 1))
-        blk = 1 + cap + cap * width                                   # floats per (source, owner) block: count | indices | rows
-        cnt = torch.zeros(N, dtype=torch.int32, device=dev)
-        idx = torch.empty((N, cap), dtype=torch.int32, device=dev)
-        rows = torch.empty((N, cap, width), dtype=torch.float32, device=dev)
+        cap = self._start_cap(("owner", P, M, N), P, P // (4 * N) + 1024)
         v = lay.views
-        if dev.type == "cuda":
+        hip = dev.type == "cuda"
+        if hip:
             import ctypes as C
             from . import _capi
             p = _capi.ptr
             di = dev.index if dev.index is not None else torch.cuda.current_device()
-            with torch.cuda.device(di):
-                _capi.check(_capi.load().lrt_grad_pack_foreign(di, P, M, N, rank, cap, p(owner), p(v["means"]), p(v["scales"]), p(v["rotations"]),
-                                                               p(v["opacities"]), p(v["shs"]), p(v["accum"]), p(idx), p(cnt), p(rows),
-                                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_grad_pack_foreign")
-        else:
-            touched = (v["accum"] > 0)
-            for d in range(N):
-                if d == rank:
-                    continue
-                g = torch.nonzero(touched & (owner == d)).squeeze(1)
-                cnt[d] = g.numel()
-                g = g[:cap]
-                idx[d, :g.numel()] = g.to(torch.int32)
-                col = 0
-                for name, k in list(GradLayout.FIELDS) + [("shs", 3 * M), ("accum", 1)]:
-                    rows[d, :g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
-                    col += k
-        # one int32 message per (source, owner) pair: count | cap indices | cap rows (bit patterns of the floats)
-        send = torch.cat([cnt.view(N, 1), idx, rows.view(torch.int32).reshape(N, cap * width)], dim=1).contiguous()
-        assert send.shape[1] == blk
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        rcnt = recv[:, 0].contiguous()
-        ridx = recv[:, 1:1 + cap].contiguous()
-        rrows = recv[:, 1 + cap:].contiguous().view(torch.float32).view(N, cap, width)
-        for s in range(N):                                            # fixed order of the sources -> a deterministic sum
-            if s == rank:
-                continue
-            if dev.type == "cuda":
+        while True:
+            blk = 1 + cap + cap * width                                   # int32 words per (source, owner) block: count | indices | rows
+            send = self._buf("own_send", (N, blk), torch.int32, dev); recv = self._buf("own_recv", (N, blk), torch.int32, dev)
+            cnt = send[:, 0]                                              # written in place: the message needs no assembly
+            idx = send[:, 1:1 + cap]
+            rows = send[:, 1 + cap:].view(torch.float32).view(N, cap, width)
+            if hip:
+                # the pack kernels address (N, cap) / (N, cap, width) arrays with their own strides: pack into contiguous scratch, copy in
+                cnt_c = self._buf("own_cnt", (N,), torch.int32, dev); idx_c = self._buf("own_idx", (N, cap), torch.int32, dev)
+                rows_c = self._buf("own_rows", (N, cap, width), torch.float32, dev)
                 with torch.cuda.device(di):
-                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(rcnt[s:s + 1]), p(ridx[s]), p(rrows[s]), p(v["means"]),
+                    _capi.check(_capi.load().lrt_grad_pack_foreign(di, P, M, N, rank, cap, p(owner), p(v["means"]), p(v["scales"]), p(v["rotations"]),
+                                                                   p(v["opacities"]), p(v["shs"]), p(v["accum"]), p(idx_c), p(cnt_c), p(rows_c),
+                                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_grad_pack_foreign")
+                cnt.copy_(cnt_c); idx.copy_(idx_c); rows.copy_(rows_c)
+            else:
+                touched = (v["accum"] > 0)
+                cnt.zero_()
+                for d in range(N):
+                    if d == rank:
+                        continue
+                    g = torch.nonzero(touched & (owner == d)).squeeze(1)
+                    cnt[d] = g.numel()
+                    g = g[:cap]
+                    idx[d, :g.numel()] = g.to(torch.int32)
+                    col = 0
+                    for name, k in self._row_fields(M):
+                        rows[d, :g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
+                        col += k
+            dist.all_to_all_single(recv, send, group=self.group)
+            rcnt = recv[:, 0].contiguous()
+            # in-step verification: no pair may have overflowed anywhere -- every rank learns the global maximum
+            worst = torch.maximum(cnt.max(), rcnt.max()).reshape(1).contiguous()
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)
+            biggest = int(self._to_host(worst)[0])
+            if biggest <= cap:
+                break
+            self.exchange_reruns += 1
+            cap = min(biggest + biggest // 4 + 1024, max(P, 1))           # the dense tensors are untouched so far: just run again
+        ridx = recv[:, 1:1 + cap]
+        rrows = recv[:, 1 + cap:].view(torch.float32).view(N, cap, width)
+        for s_ in range(N):                                               # fixed order of the sources -> a deterministic sum
+            if s_ == rank:
+                continue
+            if hip:
+                ri = ridx[s_].contiguous(); rr = rrows[s_].contiguous()
+                with torch.cuda.device(di):
+                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(rcnt[s_:s_ + 1]), p(ri), p(rr), p(v["means"]),
                                                                           p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]),
                                                                           p(v["accum"]), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                                 "lrt_grad_scatter_add_counted")
             else:
-                c = min(int(rcnt[s]), cap)
-                g = ridx[s, :c].long()
+                c = min(int(rcnt[s_]), cap)
+                g = ridx[s_, :c].long()
                 col = 0
-                for name, k in list(GradLayout.FIELDS) + [("shs", 3 * M), ("accum", 1)]:
-                    v[name].view(P, k).index_add_(0, g, rrows[s, :c, col:col + k])
+                for name, k in self._row_fields(M):
+                    v[name].view(P, k).index_add_(0, g, rrows[s_, :c, col:col + k])
                     col += k
-        # the largest count this rank saw (sent or received) travels with the next forward's slab message to every rank: it sizes
-        # later exchanges and exposes an overflow of this one
-        self._worst_dev = torch.maximum(cnt.max(), rcnt.max()).to(torch.float32).reshape(1)
-        self._worst_cap = cap
+        self._adapt_cap(biggest)
         self.last_exchange = "owner"
 
-    # ---- replicated sparse exchange ---------------------------------------------------------------------------------------------
+    # ---- replicated gathering exchange -------------------------------------------------------------------------------------------
     def _exchange_sparse(self, lay: GradLayout) -> bool:
-        """Sum the ranks' partial gradients by exchanging only the rows of touched Gaussians.
+        """Sum the ranks' partial gradients by exchanging only the rows of touched Gaussians, replicated on every rank.
 
         A Gaussian has a non-zero partial gradient on a rank only if one of that rank's rays composited it, and every
-        composited hit adds a weight > 0 to `accum` (forward.cu:268), so `accum > 0` is the exact mask.  Each rank
-        all_gathers (index, 60-float row) of its touched Gaussians (padded to the largest count), clears its buffer and
-        adds the ranks' rows in rank order: indices are unique inside a rank, so every rank ends with bit-identical
-        sums.  Returns False (nothing exchanged) when the dense all_reduce moves fewer bytes."""
-        P, M, world = lay.P, lay.M, self.world
-        fields = [(name, k) for name, k in GradLayout.FIELDS] + [("shs", 3 * M), ("accum", 1)]
-        width = sum(k for _, k in fields)
+        composited hit adds a weight > 0 to `accum` (forward.cu:268), so `accum > 0` is the exact mask.  Each rank packs
+        ``[count | indices | 60-float rows]`` of its touched Gaussians into one message of a speculated capacity (device-side
+        listing, no ``nonzero``), ONE all_gather moves the messages, the host reads the N counts (the one wait of the step: an
+        overflow re-runs with an exact capacity before anything is added), then every rank clears the rows it wrote itself --
+        the rest of the buffers is zero already -- and adds all lists in rank order: indices are unique inside a list, so every
+        rank ends with bit-identical sums.  Returns False (nothing exchanged) when ``exchange == "auto"`` and the ranks
+        together touched more than ``sparse_max_fraction`` of the Gaussians (the dense all_reduce then moves fewer bytes)."""
+        P, M, N, rank = lay.P, lay.M, self.world, self.rank
+        width = lay.width
         dev = lay.flat.device
-        idx = torch.nonzero(lay.views["accum"] > 0).squeeze(1)
-        n = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
-        counts = torch.cat(self._all_gather_rows(n)).tolist()         # the same list on every rank; ONE device->host copy
-        nmax = max(counts)
-        if self.exchange == "auto" and sum(counts) > self.sparse_max_fraction * P:
-            return False
-        pay = torch.zeros((max(nmax, 1), width), dtype=torch.float32, device=dev)
-        ids = torch.zeros(max(nmax, 1), dtype=torch.int32, device=dev)
-        m = idx.numel()
-        hip = dev.type == "cuda"                                      # HIP tensors: one pack launch and one add launch per rank
-        if m:
-            ids[:m] = idx.to(torch.int32)
+        v = lay.views
+        hip = dev.type == "cuda"
+        cap = self._start_cap(("sparse", P, M, N), P, P // (2 * N) + 1024)
+        if hip:
+            import ctypes as C
+            from . import _capi
+            p = _capi.ptr
+            di = dev.index if dev.index is not None else torch.cuda.current_device()
+            stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        while True:
+            blk = 1 + cap + cap * width
+            msg = self._buf("sp_send", (blk,), torch.int32, dev)
+            cnt, idx, rows = msg[0:1], msg[1:1 + cap], msg[1 + cap:].view(torch.float32).view(cap, width)
             if hip:
-                self._grad_rows("lrt_grad_gather", lay, m, ids, pay)
+                with torch.cuda.device(di):
+                    _capi.check(_capi.load().lrt_grad_pack_touched(di, P, M, cap, p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]),
+                                                                   p(v["shs"]), p(v["accum"]), p(idx), p(cnt), p(rows), stream()), "lrt_grad_pack_touched")
             else:
+                g = torch.nonzero(v["accum"] > 0).squeeze(1)
+                cnt[0] = g.numel()
+                g = g[:cap]
+                idx[:g.numel()] = g.to(torch.int32)
                 col = 0
-                for name, k in fields:
-                    pay[:m, col:col + k] = lay.views[name].reshape(P, k).index_select(0, idx)
+                for name, k in self._row_fields(M):
+                    rows[:g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
                     col += k
-        pays, idss = self._all_gather_rows(pay), self._all_gather_rows(ids)
-        lay.flat.zero_()
-        for r in range(world):                                        # fixed order -> identical rounding on every rank
+            parts = self._all_gather_rows(msg)
+            counts = [int(c) for c in self._to_host(torch.stack([q[0] for q in parts]))]
+            biggest = max(counts)
+            if biggest <= cap:
+                break
+            self.exchange_reruns += 1
+            cap = min(biggest + biggest // 4 + 1024, max(P, 1))
+        if self.exchange == "auto" and sum(counts) > self.sparse_max_fraction * P:
+            self._adapt_cap(biggest)
+            return False                                                  # nothing was modified: the caller all-reduces the flat buffer
+        # clear what this rank wrote (its own touched rows), then add every rank's list in rank order
+        if hip:
+            with torch.cuda.device(di):
+                _capi.check(_capi.load().lrt_grad_zero_rows_counted(di, P, M, cap, p(cnt), p(idx), p(v["means"]), p(v["scales"]), p(v["rotations"]),
+                                                                    p(v["opacities"]), p(v["shs"]), p(v["accum"]), stream()), "lrt_grad_zero_rows_counted")
+        else:
+            g = idx[:counts[rank]].long()
+            for name, k in self._row_fields(M):
+                v[name].view(P, k).index_fill_(0, g, 0.0)
+        for r in range(N):
             c = counts[r]
             if c == 0:
                 continue
+            q = parts[r]
+            ridx, rrows = q[1:1 + cap], q[1 + cap:].view(torch.float32).view(cap, width)
             if hip:
-                self._grad_rows("lrt_grad_scatter_add", lay, c, idss[r], pays[r])
-                continue
-            ridx = idss[r][:c].long()
-            col = 0
-            for name, k in fields:
-                lay.views[name].view(P, k).index_add_(0, ridx, pays[r][:c, col:col + k])
-                col += k
+                with torch.cuda.device(di):
+                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(q[0:1]), p(ridx), p(rrows), p(v["means"]), p(v["scales"]),
+                                                                          p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]), stream()),
+                                "lrt_grad_scatter_add_counted")
+            else:
+                g = ridx[:c].long()
+                col = 0
+                for name, k in self._row_fields(M):
+                    v[name].view(P, k).index_add_(0, g, rrows[:c, col:col + k])
+                    col += k
+        self._adapt_cap(biggest)
         self.last_exchange = "sparse"
         return True

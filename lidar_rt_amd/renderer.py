@@ -31,6 +31,38 @@ def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 use_fused_preprocess = True   # module switch: False forces the getter chain of the reference (used by the tests)
 
+# Multi-GPU: set to a lidar_rt_amd.parallel.ShardedTracer and raytracing() traces this rank's azimuth slab only, all-gathers the
+# image and, in the backward, exchanges the gradient rows so that EVERY rank holds the full image, the full gradients and the full
+# `accum_gaussian_weight` -- train.py's loop (losses, scene.optimize: Adam, densification, pruning) then runs unchanged and identically
+# on every rank (lidar_rt_amd.parallel.ShardedTracer: exchange "sparse" or "dense"; not "owner", whose gradients are not replicated).
+sharded = None
+
+
+class _ShardedTrace(torch.autograd.Function):
+    """The operator of `_Tracer` (diff_lidar_tracer/__init__.py) across the ranks of a ShardedTracer: forward = local slab + slab
+    all_gather, backward = local backward + gradient exchange.  `accum_out` (P,) receives this rank's partial hit weights in the
+    forward and the complete ones in the backward (train.py:215-220 reads them after loss.backward())."""
+
+    @staticmethod
+    def forward(ctx, st, ray_o, ray_d, means3D, scales, rotations, opacity, shs, deg, bg, accum_out):
+        if st.world > 1 and st.exchange == "owner":
+            raise ValueError("renderer.sharded needs a replicated gradient exchange ('sparse', 'dense' or 'auto'), not 'owner'")
+        a = [t.detach().contiguous() for t in (means3D, scales, rotations, opacity, shs)]
+        out, accum_loc = st.forward(ray_o.contiguous(), ray_d.contiguous(), a[0], a[1], a[2], a[3], a[4], int(deg), bg)
+        accum_out.copy_(accum_loc.reshape(accum_out.shape))
+        ctx.st, ctx.deg, ctx.bg, ctx.accum_out = st, int(deg), bg, accum_out
+        ctx.save_for_backward(*a)
+        return out
+
+    @staticmethod
+    def backward(ctx, dL):
+        means, scales, rotations, opacity, shs = ctx.saved_tensors
+        g = ctx.st.backward(means, scales, rotations, opacity, shs, ctx.deg, ctx.bg, dL.contiguous())
+        ctx.accum_out.copy_(g["accum"].reshape(ctx.accum_out.shape))
+        # the views belong to a buffer the next step reuses: hand autograd its own copies
+        return (None, None, None, g["means"].clone(), g["scales"].clone(), g["rotations"].clone(),
+                g["opacities"].reshape(opacity.shape).clone(), g["shs"].clone(), None, None, None)
+
 
 def _fused_inputs(frame, assets, dynamic, decomp):
     """Raw parameters of GaussianModel-like assets (`_xyz`, `_scaling`, `_rotation`, `_opacity`, `bounding_box.frame`)
@@ -59,11 +91,12 @@ def _fused_inputs(frame, assets, dynamic, decomp):
 def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifier=1.0, override_color=None,
                decomp=False):
     global tracer_2dgs
-    if tracer_2dgs is None:
-        tracer_2dgs = Tracer()
-    # opt.bvh_refit_interval = K > 0: K refits (lrt_refit: same order and topology, new records and boxes) between full LBVH
-    # builds while the number of Gaussians is unchanged; results do not depend on it.  0 = rebuild every call (the reference)
-    tracer_2dgs.optix_context.refit_interval = int(getattr(getattr(args, "opt", None), "bvh_refit_interval", 0) or 0)
+    if sharded is None:
+        if tracer_2dgs is None:
+            tracer_2dgs = Tracer()
+        # opt.bvh_refit_interval = K > 0: K refits (lrt_refit: same order and topology, new records and boxes) between full LBVH
+        # builds while the number of Gaussians is unchanged; results do not depend on it.  0 = rebuild every call (the reference)
+        tracer_2dgs.optix_context.refit_interval = int(getattr(getattr(args, "opt", None), "bvh_refit_interval", 0) or 0)
     if decomp == "background":
         gaussian_assets = gaussian_assets[:1]
     elif decomp == "object":
@@ -109,11 +142,17 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
         means3D.retain_grad()          # train.py:219 reads means3D.grad
     except Exception:
         pass
-    # fused replacement of primitiveCallback(...) + tracer.build_acceleration_structure(vertices, faces, rebuild=True)
-    tracer_2dgs.build_from_gaussians(means3D, scales, rotations, opacity)
-    rendered, accum = tracer_2dgs(ray_o=rays_o, ray_d=rays_d, mesh_normals=None, means3D=means3D, grads3D=grads3D,
-                                  shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
-                                  rotations=rotations, cov3Ds_precomp=None, tracer_settings=settings)
+    if sharded is not None:
+        # this rank's azimuth slab + collectives (build, trace and exchange inside ShardedTracer); same outputs on every rank
+        accum = torch.zeros(means3D.shape[0], dtype=torch.float32, device=means3D.device)
+        rendered = _ShardedTrace.apply(sharded, rays_o, rays_d, means3D, scales, rotations, opacity, shs,
+                                       gaussian_assets[0].active_sh_degree, settings.bg, accum)
+    else:
+        # fused replacement of primitiveCallback(...) + tracer.build_acceleration_structure(vertices, faces, rebuild=True)
+        tracer_2dgs.build_from_gaussians(means3D, scales, rotations, opacity)
+        rendered, accum = tracer_2dgs(ray_o=rays_o, ray_d=rays_d, mesh_normals=None, means3D=means3D, grads3D=grads3D,
+                                      shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
+                                      rotations=rotations, cov3Ds_precomp=None, tracer_settings=settings)
     intensities, rayhit_logits = rendered[:, :, 0:1], rendered[:, :, 1:2]
     raydrop_logits, depth = rendered[:, :, 2:3], rendered[:, :, 3:4]
     if getattr(getattr(args, "opt", None), "use_rayhit", False):

@@ -449,8 +449,9 @@ def training_step(scene: GaussianScene, frames: RangeFrames, frame, iteration: i
     regularisation, backward, then ``scene.optimize`` with ``means3D.grad`` and the accumulated hit weights.
     ``chamfer_points_detached``: the reference builds both point clouds from numpy (lidar_sensor.py:182-183), so its
     Chamfer term carries no gradient; False keeps the predicted points differentiable."""
-    from .chamfer3D import chamfer_3DDist
     from .renderer import raytracing
+    if opt.lambda_cd != 0:
+        from .chamfer3D import chamfer_3DDist
     scene.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         scene.oneupSHdegree()
@@ -470,11 +471,14 @@ def training_step(scene: GaussianScene, frames: RangeFrames, frame, iteration: i
                 + opt.lambda_intensity_dssim * (1 - ssim((intensity * mf).unsqueeze(0), (gt_int * mf).unsqueeze(0))))
     labels = (1.0 - mf).reshape(-1, 1)                                # 1 = dropped ray (train.py:188-193)
     loss_drop = opt.lambda_raydrop_bce * F.binary_cross_entropy(raydrop.reshape(-1, 1).clamp(1e-7, 1 - 1e-7), labels)
-    pred_depth = depth.detach() if chamfer_points_detached else depth
-    gt_pts = frames.inverse_projection_with_range(frame, gt_depth)
-    pred_pts = frames.inverse_projection_with_range(frame, pred_depth)
-    d1, d2, _, _ = chamfer_3DDist()(pred_pts[None].contiguous(), gt_pts[None].contiguous())
-    loss_cd = opt.lambda_cd * (d1 + d2).mean() * 0.5
+    if opt.lambda_cd != 0:
+        pred_depth = depth.detach() if chamfer_points_detached else depth
+        gt_pts = frames.inverse_projection_with_range(frame, gt_depth)
+        pred_pts = frames.inverse_projection_with_range(frame, pred_depth)
+        d1, d2, _, _ = chamfer_3DDist()(pred_pts[None].contiguous(), gt_pts[None].contiguous())
+        loss_cd = opt.lambda_cd * (d1 + d2).mean() * 0.5
+    else:                                                             # weight 0: the term (and its HIP operator) is skipped
+        loss_cd = torch.zeros((), device=depth.device)
     loss_reg = sum(opt.lambda_reg * g.box_reg_loss() for g in scene.gaussians_assets)
     loss = loss_depth + loss_int + loss_drop + loss_cd + loss_reg
     loss.backward()

@@ -71,3 +71,40 @@ def test_sharded_equals_single(tmp_path, world, exchange):
         for k in ("means", "scales", "rotations", "opacities", "shs", "accum"):
             ref = g1[k].numpy()
             np.testing.assert_allclose(res[k], ref, rtol=1e-4, atol=1e-6 * max(np.abs(ref).max(), 1e-30))
+
+
+def _run_training_worker(tmp_path, tag, world, device="cpu", exchange="sparse", port=29560, **env_extra):
+    base = str(tmp_path / tag)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **env_extra)
+    worker = os.path.join(REPO, "tests", "train_dist_worker.py")
+    if world == 1:
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        cmd = [sys.executable, worker, base, device, exchange]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port + world), worker, base, device, exchange]
+    subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=900)
+    return [np.load(base + f".rank{r}.npz") for r in range(world)]
+
+
+PARAMS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
+@pytest.mark.parametrize("world,exchange,first_cap", [(2, "sparse", None), (3, "sparse", None), (2, "dense", None), (3, "sparse", "40")])
+def test_sharded_training_steps_equal_the_single_rank_run(tmp_path, world, exchange, first_cap):
+    """K = 5 `training_step`s incl. one densification (clones, splits, opacity pruning) through `renderer.sharded`
+    on N gloo ranks: every rank ends with the single-rank parameters (<= 1e-6), the same number of Gaussians, and the replicas are
+    bit-identical to each other (losses, Adam and the densification decisions run replicated on replicated gradients).  With a first
+    capacity that is too small the exchange verifies its counts inside the step and runs again: same result."""
+    single = _run_training_worker(tmp_path, "single", 1)[0]
+    assert single["log"][2, 2] > 0 and single["log"][2, 3] > 0 and single["log"][2, 5] > 0, "the case must clone, split and prune"
+    extra = {"LRT_TEST_FIRST_CAP": first_cap} if first_cap else {}
+    ranks = _run_training_worker(tmp_path, f"w{world}", world, exchange=exchange, **extra)
+    for r, res in enumerate(ranks):
+        np.testing.assert_array_equal(res["log"][:, 1:], single["log"][:, 1:])               # P and the clone / split / prune counts per step
+        for k in PARAMS + ("m_xyz", "v_xyz"):
+            assert res[k].shape == single[k].shape, (r, k)
+            np.testing.assert_array_equal(res[k], ranks[0][k])                                 # replicas never diverge
+            np.testing.assert_allclose(res[k], single[k], rtol=0, atol=1e-6 * max(np.abs(single[k]).max(), 1.0))
+        if first_cap:
+            assert int(res["reruns"][0]) >= 1, "the undersized first exchange must have been re-run"

@@ -17,9 +17,21 @@ def test_image_and_raydrop_metrics_match_numpy_restatements():
     g, p = np.clip(gt, 1e-6, 80), np.clip(pred, 1e-6, 80)                       # eval.py:282-297
     assert abs(float(m["rmse"]) - np.sqrt(((g - p) ** 2).mean())) < 1e-5
     assert abs(float(m["mae"]) - np.abs(g - p).mean()) < 1e-5
-    assert abs(float(m["medae"]) - np.median(np.abs(g - p))) < 2e-3             # torch's median takes the lower middle element
+    assert abs(float(m["medae"]) - np.median(np.abs(g - p))) < 1e-6
     assert abs(float(m["psnr"]) - 10 * np.log10(80 ** 2 / ((p - g) ** 2).mean())) < 1e-3
-    assert 0.0 < float(m["ssim"]) <= 1.0
+    # SSIM: a scipy restatement of skimage.metrics.structural_similarity's defaults (7x7 uniform filter, sample covariance,
+    # border cropped), which is what eval.py:299-301 calls with data_range = max(gt) - min(gt)
+    from scipy.ndimage import uniform_filter
+    def sk_ssim(x, y, R, win=7):
+        x = x.astype(np.float64); y = y.astype(np.float64)
+        f = lambda a: uniform_filter(a, size=win, mode="reflect")
+        ux, uy = f(x), f(y); n = win * win / (win * win - 1.0)
+        vx, vy, vxy = n * (f(x * x) - ux * ux), n * (f(y * y) - uy * uy), n * (f(x * y) - ux * uy)
+        C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        pad = (win - 1) // 2
+        return S[pad:-pad, pad:-pad].mean()
+    assert abs(float(m["ssim"]) - sk_ssim(p, g, g.max() - g.min())) < 1e-5
     assert float(evaluation.depth_metrics(torch.tensor(gt), torch.tensor(gt))["ssim"]) > 0.999
     gd = (rng.uniform(size=2000) < 0.3).astype(np.float32); pd = np.where(rng.uniform(size=2000) < 0.9, gd, 1 - gd).astype(np.float32)
     r = evaluation.raydrop_metrics(torch.tensor(gd), torch.tensor(pd))            # eval.py:333-349
@@ -49,10 +61,11 @@ def test_batched_evaluation_of_a_scene_against_its_own_rendering():
         rays[f] = (t(o), t(d))
         frames.add_frame(f, rays[f][0], rays[f][1], torch.zeros(H, W, device=DEV), torch.zeros(H, W, device=DEV), torch.ones(H, W, device=DEV))
     first = evaluation.render_frames([asset], frames, range(6), bg)
-    for f in range(6):                                                            # ground truth = the scene's own rendering
-        frames.add_frame(f, rays[f][0], rays[f][1], first[f]["depth"].squeeze(-1).clone(), first[f]["intensity"].squeeze(-1).clamp(0, 1).clone(),
-                         first[f]["raydrop"].squeeze(-1) < 0.5)
-    res = evaluation.evaluate([asset], frames, list(range(6)), bg)
+    thr = float(torch.cat([first[f]["raydrop"].flatten() for f in range(6)]).median())   # a ray-drop threshold that splits this synthetic scene's rays
+    for f in range(6):                                                            # ground truth = the scene's own rendering, masked like eval.py:224, :238
+        hit = first[f]["raydrop"].squeeze(-1) < thr
+        frames.add_frame(f, rays[f][0], rays[f][1], first[f]["depth"].squeeze(-1) * hit, first[f]["intensity"].squeeze(-1).clamp(0, 1) * hit, hit)
+    res = evaluation.evaluate([asset], frames, list(range(6)), bg, raydrop_ratio=thr)
     assert res["mean"]["depth"]["rmse"] < 1e-5 and res["mean"]["intensity"]["rmse"] < 1e-6
     assert res["mean"]["raydrop"]["acc"] == 1.0 and res["mean"]["points"]["fscore"] > 0.999 and res["mean"]["points"]["chamfer_dist"] < 1e-8
     assert res["mean"]["depth"]["ssim"] > 0.999
