@@ -104,9 +104,14 @@ def points_metrics(gt_pts: torch.Tensor, pred_pts: torch.Tensor, threshold: floa
         z = torch.zeros((), device=gt_pts.device)
         return {"chamfer_dist": z + float("nan"), "fscore": z}
     d1, d2, _, _ = chamfer_3DDist()(gt_pts[None].float().contiguous(), pred_pts[None].float().contiguous())
-    p1 = (d1 < threshold).float().mean(); p2 = (d2 < threshold).float().mean()
+    return {"chamfer_dist": d1.mean() + d2.mean(), "fscore": fscore(d1, d2, threshold)[0]}
+
+
+def fscore(dist1: torch.Tensor, dist2: torch.Tensor, threshold: float = 0.001):
+    """eval.py:266-280 ``compute_fscore`` on squared nearest distances (B, N) / (B, M): (fscore, precision_1, precision_2), NaN -> 0."""
+    p1 = (dist1 < threshold).float().mean(dim=-1); p2 = (dist2 < threshold).float().mean(dim=-1)
     f = 2 * p1 * p2 / (p1 + p2)
-    return {"chamfer_dist": d1.mean() + d2.mean(), "fscore": torch.nan_to_num(f, nan=0.0)}
+    return torch.nan_to_num(f, nan=0.0).reshape(-1)[0], p1.reshape(-1)[0], p2.reshape(-1)[0]
 
 
 def evaluate(gaussian_assets: Sequence, sensor, frame_ids: Sequence, background: torch.Tensor, args=None,

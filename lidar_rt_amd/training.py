@@ -149,11 +149,15 @@ class GaussianAsset:
                 g["lr"] = lr
         return lr
 
-    def _rewrite(self, new_value, keep_state):
-        """Replace every optimised tensor by ``new_value(name, old)`` and its Adam moments by ``keep_state(name, moment)``
-        (the optimiser surgery behind pruning, densification and the opacity reset, gaussian_model.py:227-289)."""
-        out = {}
+    def _rewrite(self, new_value, keep_state, only=None):
+        """Replace every optimised tensor (or only the group `only`) by ``new_value(name, old)`` and its Adam moments by
+        ``keep_state(name, moment)`` (the optimiser surgery behind pruning, densification and the opacity reset,
+        gaussian_model.py:227-289).  A replaced tensor is a NEW Parameter without a gradient: the optimiser step that follows in the
+        same iteration skips it, exactly like the reference's."""
+        out = dict(self._params())
         for g in self.optimizer.param_groups:
+            if only is not None and g["name"] != only:
+                continue
             old = g["params"][0]
             st = self.optimizer.state.pop(old, None)
             new = nn.Parameter(new_value(g["name"], old.detach()).contiguous().requires_grad_(True))
@@ -179,7 +183,8 @@ class GaussianAsset:
     def reset_opacity(self):
         """Opacities are pulled down to <= 0.01 and their Adam moments restart (gaussian_model.py:216-219)."""
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01)).detach()
-        self._rewrite(lambda n, t: new if n == "opacity" else t, lambda n, m: torch.zeros_like(m) if n == "opacity" else m)
+        # only the opacity group is replaced (replace_tensor_to_optimizer): the other five keep their gradients and are stepped
+        self._rewrite(lambda n, t: new, lambda n, m: torch.zeros_like(m), only="opacity")
 
     # ---- densification --------------------------------------------------------------------------------------------
     def add_densification_stats(self, mean_grads: torch.Tensor, update_filter: torch.Tensor):

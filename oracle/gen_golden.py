@@ -12,6 +12,13 @@ TEST INFRASTRUCTURE.  Two kinds of vectors are written:
      lib/utils/primitive_utils.py: build2DRectangle
      lib/scene/lidar_sensor.py  : LiDARSensor.get_range_rays (KITTI + Waymo mode)
    -> tests/golden/conventions.npz, rays_*.npz
+   lib/scene/gaussian_model.py : GaussianModel (training_setup, Adam groups, learning-rate schedule, add_densification_stats,
+                                 densify_and_prune incl. the tracking-box rule, reset_opacity, capture) driven through the
+                                 sequence of calls of SceneLidar.optimize (lib/dataloader/gs_loader.py:243-298)
+   lib/utils/loss_utils.py    : l1_loss, l2_loss, ssim, BinaryCrossEntropyLoss
+   eval.py                    : LiDARRTMeter.compute_raydrop_metrics / compute_fscore (the metric methods that need no
+                                 third-party package; depth / intensity SSIM is skimage's, LPIPS a pretrained network)
+   -> tests/golden/loop_golden.npz   (`--only-loop`)
 2. *Oracle regression vectors* -- outputs of our CPU restatement
    (oracle/lrt_oracle.c, float32) on the seeded S10k scene
    -> tests/golden/s10k_golden.npz, s1m_stats.json.
@@ -245,16 +252,141 @@ def gen_preprocess_pins():
     print("preprocess_golden.npz written")
 
 
+def gen_loop_pins():
+    """tests/golden/loop_golden.npz: the training-loop bookkeeping of the reference executed with the reference's own classes on CPU
+    (inputs + expected outputs only).  lidar_rt_amd/training.py and evaluation.py are tested against it (tests/test_loop_golden.py)."""
+    torch, gu, shu, pu, ls, mode = _import_reference()
+    from types import SimpleNamespace
+    from torch import nn
+    from lib.scene import gaussian_model as gm
+    from lib.utils import loss_utils as lu
+    from lidar_rt_amd.training import default_options        # the hyper-parameter VALUES (configs/base.yaml, configs/exp.yaml) as one namespace
+    out = {}
+    opt = default_options()
+    opt.densify_grad_threshold, opt.densify_scale_threshold, opt.thresh_opa_prune = 4e-4, 0.012, 0.2
+    out["opt_densify_grad_threshold"], out["opt_densify_scale_threshold"], out["opt_thresh_opa_prune"] = 4e-4, 0.012, 0.2
+
+    def make(P, seed, bbox=None):
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s: torch.randn(*s, generator=g)
+        m = gm.GaussianModel(2, 3, extent=10.0, bounding_box=bbox)
+        m.spatial_lr_scale = 10.0                               # create_from_pcd sets it to the extent (gaussian_model.py:156)
+        init = {"xyz": r(P, 3) * 2.0, "f_dc": r(P, 1, 3), "f_rest": r(P, 15, 3) * 0.1, "opacity": r(P, 1), "scaling": r(P, 2) * 0.7 - 2.2, "rotation": r(P, 4)}
+        m._xyz, m._features_dc, m._features_rest = nn.Parameter(init["xyz"].clone()), nn.Parameter(init["f_dc"].clone()), nn.Parameter(init["f_rest"].clone())
+        m._opacity, m._scaling, m._rotation = nn.Parameter(init["opacity"].clone()), nn.Parameter(init["scaling"].clone()), nn.Parameter(init["rotation"].clone())
+        m.max_radii2D = torch.zeros(P)
+        return m, init, g
+
+    def params(m):
+        return {"xyz": m._xyz, "f_dc": m._features_dc, "f_rest": m._features_rest, "opacity": m._opacity, "scaling": m._scaling, "rotation": m._rotation}
+
+    def drive(tag, m, g, iters, densify_at, reset_at, size_threshold):
+        """The call sequence of SceneLidar.optimize for one asset, with seeded stand-ins for loss.backward()'s gradients."""
+        m.training_setup(opt)
+        out[tag + "_group_names"] = np.array([gr["name"] for gr in m.optimizer.param_groups])
+        out[tag + "_group_lrs"] = np.array([gr["lr"] for gr in m.optimizer.param_groups], np.float64)
+        out[tag + "_adam_eps"] = np.float64(m.optimizer.defaults["eps"])
+        its = [0, 1, 10, 1000, 15000, 30000, 40000]
+        out[tag + "_lr_iters"] = np.array(its); out[tag + "_lr_xyz"] = np.array([m.update_learning_rate(i) for i in its], np.float64)
+        log = []
+        for it in range(1, iters + 1):
+            m.update_learning_rate(it)
+            P = m._xyz.shape[0]
+            grads = {n: torch.randn(p_.shape, generator=g) * 0.01 for n, p_ in params(m).items()}
+            mean_grads = torch.randn(P, 3, generator=g) * 1e-3
+            accum = (torch.rand(P, 1, generator=g) < 0.6).float() * torch.rand(P, 1, generator=g)
+            for n, p_ in params(m).items():
+                p_.grad = grads[n].clone()
+                out[f"{tag}_it{it}_grad_{n}"] = grads[n].numpy()
+            out[f"{tag}_it{it}_mean_grads"] = mean_grads.numpy(); out[f"{tag}_it{it}_accum"] = accum.numpy()
+            with torch.no_grad():
+                m.add_densification_stats(mean_grads, accum > 0)
+                info = (0, 0, 0, 0)
+                if it == densify_at:
+                    torch.manual_seed(4242)                          # the split's (and the box rule's) torch.normal draws
+                    info = m.densify_and_prune(opt, 0.005, size_threshold)
+                if it == reset_at:
+                    m.reset_opacity()
+                m.optimizer.step()
+                m.optimizer.zero_grad(set_to_none=True)
+            log.append([m._xyz.shape[0]] + [int(x) for x in info])
+            for n, p_ in params(m).items():
+                out[f"{tag}_it{it}_param_{n}"] = p_.detach().numpy().copy()
+            st = m.optimizer.state
+            for n, p_ in params(m).items():
+                if p_ in st:
+                    out[f"{tag}_it{it}_m_{n}"] = st[p_]["exp_avg"].numpy().copy(); out[f"{tag}_it{it}_v_{n}"] = st[p_]["exp_avg_sq"].numpy().copy()
+            out[f"{tag}_it{it}_grad_accum"] = m.xyz_gradient_accum.numpy().copy(); out[f"{tag}_it{it}_denom"] = m.denom.numpy().copy()
+        out[tag + "_log"] = np.array(log)
+        cap = m.capture()
+        out[tag + "_capture_types"] = np.array([type(c).__name__ for c in cap])
+        out[tag + "_capture_shapes"] = np.array([str(tuple(c.shape)) if hasattr(c, "shape") else "" for c in cap])
+        out[tag + "_capture_state_keys"] = np.array(sorted(cap[10].keys()))
+        return m
+
+    # A: the background asset (no tracking box), densification at iteration 3 with the size rule, opacity reset at 5
+    m, init, g = make(200, 11)
+    for n, v in init.items(): out["A_init_" + n] = v.numpy()
+    drive("A", m, g, 6, 3, 5, 20)
+    # B: an actor with a tracking box (points outside the box are pruned with random samples), densification at 2
+    from lib.scene.bounding_box import BoundingBox
+    bb = BoundingBox("car", 7, np.array([3.0, 2.5, 2.0], np.float32))
+    m, init, g = make(150, 12, bb)
+    for n, v in init.items(): out["B_init_" + n] = v.numpy()
+    out["B_box_size"] = np.array([3.0, 2.5, 2.0], np.float32)
+    drive("B", m, g, 3, 2, -1, 20)
+    with torch.no_grad():
+        out["B_box_reg_loss"] = np.float64(m.box_reg_loss())
+
+    # losses (lib/utils/loss_utils.py) on seeded images
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(1, 16, 64, generator=g); b = (a + 0.1 * torch.randn(1, 16, 64, generator=g)).clamp(0, 1)
+    out["loss_img_a"], out["loss_img_b"] = a.numpy(), b.numpy()
+    out["loss_l1"], out["loss_l2"], out["loss_ssim"] = np.float64(lu.l1_loss(a, b)), np.float64(lu.l2_loss(a, b)), np.float64(lu.ssim(a, b))
+    labels = (torch.rand(1024, 1, generator=g) < 0.3); preds = torch.rand(1024, 1, generator=g).clamp(1e-4, 1 - 1e-4)
+    out["bce_labels"], out["bce_preds"] = labels.numpy(), preds.numpy()
+    out["loss_bce"] = np.float64(lu.BinaryCrossEntropyLoss()(labels, preds=preds))
+    # eval.py's own metric methods (no third-party package inside)
+    try:
+        for name in ["diff_lidar_tracer", "tensorflow", "waymo_open_dataset", "lib.utils.chamfer3D", "lib.utils.chamfer3D.dist_chamfer_3D", "lib.gaussian_renderer",
+                     "lib.dataloader", "lib.arguments", "lib.scene.unet", "lib.utils.image_utils"]:
+            if name not in sys.modules:
+                sys.modules[name] = type(sys.modules["plyfile"])(name) if "plyfile" in sys.modules and not hasattr(sys.modules["plyfile"], "__file__") else types.ModuleType(name)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "eval.py"))
+        ev = importlib.util.module_from_spec(spec); spec.loader.exec_module(ev)
+        me = SimpleNamespace(raydrop_ratio=0.4)
+        rng = np.random.default_rng(9)
+        gt = (rng.uniform(size=(16, 64, 1)) < 0.3).astype(np.float64); pr = np.where(rng.uniform(size=gt.shape) < 0.85, gt, 1 - gt)
+        out["eval_drop_gt"], out["eval_drop_pred"] = gt, pr
+        out["eval_raydrop_metrics"] = np.array(ev.LiDARRTMeter.compute_raydrop_metrics(me, gt, pr), np.float64)
+        d1 = torch.from_numpy(rng.uniform(0, 0.2, (1, 500)) ** 2); d2 = torch.from_numpy(rng.uniform(0, 0.3, (1, 400)) ** 2)
+        f, p1, p2 = ev.LiDARRTMeter.compute_fscore(me, d1, d2, threshold=0.05)
+        out["eval_dist1"], out["eval_dist2"] = d1.numpy(), d2.numpy()
+        out["eval_fscore"] = np.array([float(f[0]), float(p1[0]), float(p2[0])])
+        print("eval.py metric methods pinned")
+    except Exception as ex:                                        # eval.py drags half the repository in at import time
+        print("eval.py not importable under the shim, its metric methods stay unpinned:", repr(ex)[:200])
+    mode.__exit__(None, None, None)
+    np.savez_compressed(os.path.join(OUT, "loop_golden.npz"), **out)
+    print("loop_golden.npz written:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-loop", action="store_true")
     ap.add_argument("--only-preprocess", action="store_true")
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--s1m", action="store_true", help="also compute S1M statistics (needs ~1 min)")
     a = ap.parse_args()
+    if a.only_loop:
+        gen_loop_pins()
+        sys.exit(0)
     if a.only_preprocess:
         gen_preprocess_pins()
         sys.exit(0)
     if not a.skip_reference:
         gen_reference_pins()
         gen_preprocess_pins()
+        gen_loop_pins()
     gen_oracle_vectors(a.s1m)
