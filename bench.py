@@ -128,6 +128,11 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
                     "at least this long (one window, bracketed once; `steps` in the output is what ran, `steps_requested` what was asked); 0 = exactly --steps")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
+    ap.add_argument("--via", default="direct", choices=["direct", "tracer"], help="direct (default): the step drives the `_C` binding through ShardedTracer "
+                    "with preallocated gradient views; tracer: the DROP-IN path a maintainer gets -- diff_lidar_tracer.Tracer -> torch.autograd -> `_C` "
+                    "(fresh output / gradient tensors per call, the three dead zero outputs), N = 1 only.  The line always carries the other path's "
+                    "rays/s as `drop_in_path` / `direct_path` when --both-paths is given")
+    ap.add_argument("--both-paths", action="store_true", help="time the other --via path too (same window length) and report it beside `value`")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
                     "configuration: the reference rebuilds its acceleration structure on every call, and so does the default step)")
@@ -177,11 +182,35 @@ def main():
         st.set_option(k_, int(v_))
     st.refit_interval = max(args.refit_every, 0)
 
-    def step():
+    def step_direct():
         out, _ = tr.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg,
                             rebuild=not args.no_build_in_step)
         g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
         return out, g
+
+    # the drop-in path: what lib/gaussian_renderer/__init__.py:142-160 + loss.backward() execute per iteration
+    from lidar_rt_amd.diff_lidar_tracer import Tracer, TracingSettings, _C as _binding
+    drop = {"tracer": None}
+
+    def step_tracer():
+        if drop["tracer"] is None:
+            trc = Tracer(); trc.optix_context = st                      # the same state object (options, timing, statistics)
+            e_ = torch.empty(0, device=dev)
+            drop["tracer"] = (trc, TracingSettings(None, None, None, None, bg, 1.0, e_, e_, deg, torch.zeros(3, device=dev), False, False),
+                              {k: v.detach().clone().requires_grad_(True) for k, v in t.items()})
+        trc, ts_, leaf = drop["tracer"]
+        for v in leaf.values():
+            v.grad = None
+        if not args.no_build_in_step:
+            trc.build_from_gaussians(leaf["means"], leaf["scales"], leaf["rotations"], leaf["opacities"])
+        out, acc = trc(ray_o, ray_d, None, leaf["means"], torch.zeros_like(leaf["means"]), shs=leaf["shs"], opacities=leaf["opacities"],
+                       scales=leaf["scales"], rotations=leaf["rotations"], tracer_settings=ts_)
+        out.backward(dL)
+        return out.detach(), {"means": leaf["means"].grad, "shs": leaf["shs"].grad, "accum": acc}
+
+    if args.via == "tracer" and world > 1:
+        raise SystemExit("--via tracer is the single-GPU drop-in path; N > 1 runs through ShardedTracer (renderer.sharded for training)")
+    step = step_tracer if args.via == "tracer" else step_direct
 
     if args.no_build_in_step:
         tr.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
@@ -221,6 +250,16 @@ def main():
     st.enable_timing(False)
     phases = tr.phase_timing()
     tr.enable_phase_timing(False)
+
+    other = None
+    if args.both_paths and world == 1:
+        ostep = step_direct if args.via == "tracer" else step_tracer
+        for _ in range(max(args.warmup, 1)):
+            ostep()
+        barrier(); t1 = time.perf_counter()
+        for _ in range(steps_run):
+            ostep()
+        barrier(); other = H * W * steps_run / (time.perf_counter() - t1)
 
     # ---------------- one instrumented step for the traversal statistics (untimed)
     st.enable_stats(True)
@@ -299,13 +338,15 @@ def main():
                        "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
                                + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (counts verified inside the step: one small device->host read)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
-                       "gradient_exchange": tr.last_exchange},
+                       "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND},
             "roofline": roof,
             # per-phase GPU time per step on rank 0 (HIP events): LBVH build / forward trace / backward; N > 1: + slab all_gather and
             # gradient exchange (torch events around the collectives and their pack / unpack kernels)
             "phase_ms": {"build": ms_build, "forward": ms_f, "backward": ms_b, **{k: v for k, v in phases.items()}},
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }
+        if other is not None:
+            res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_run}
         if args.check_sum:
             res["checksums"] = cks
         if world == 1 and not args.no_cpu_baseline:

@@ -1,7 +1,11 @@
-"""Build liblrt_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+"""Build the native pieces in-tree:
 
-The library has no torch dependency; it is loaded through ctypes
-(``lidar_rt_amd._capi``).  ``python -m lidar_rt_amd.build`` rebuilds it.
+* ``csrc/liblrt_hip.so``  -- HIP kernels + C ABI (hipcc --offload-arch=gfx950).  No torch dependency; loadable through ctypes
+  (``lidar_rt_amd._capi``).
+* ``diff_lidar_tracer/_C_ext.*.so`` -- the PyTorch-ROCm C++ extension (pybind11, ``csrc/lrt_torch_ext.cpp``): the reference's
+  ``_C`` module surface with at::Tensor arguments on top of the C ABI.  Host code only; it links liblrt_hip.so.
+
+``python -m lidar_rt_amd.build`` rebuilds what is stale (``--force``: everything).
 """
 from __future__ import annotations
 
@@ -44,7 +48,52 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+EXT_SRC = os.path.join(CSRC, "lrt_torch_ext.cpp")
+EXT_DIR = os.path.join(HERE, "diff_lidar_tracer")
+
+
+def ext_path() -> str:
+    import sysconfig
+    return os.path.join(EXT_DIR, "_C_ext" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def ext_is_stale() -> bool:
+    out = ext_path()
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(f) > t for f in (EXT_SRC, os.path.join(HERE, "..", "include", "lrt.h")))
+
+
+def build_ext(force: bool = False, verbose: bool = False) -> str:
+    """The torch extension: one host-only C++ file against torch's headers (the include / library paths torch.utils.cpp_extension
+    reports), linked with liblrt_hip.so through an $ORIGIN-relative rpath so that the in-tree pair travels together."""
+    out = ext_path()
+    if not force and not ext_is_stale():
+        return out
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    rocm = os.environ.get("ROCM_HOME") or os.environ.get("ROCM_PATH") or "/opt/rocm"
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", f"-I{sysconfig.get_paths()['include']}"]
+    libdirs = ce.library_paths() + [f"{rocm}/lib"]
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C_ext",
+            "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}"] + inc + [EXT_SRC, "-o", out]
+           + [f"-L{d}" for d in libdirs] + [f"-L{CSRC}", "-llrt_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN/../csrc"] + [f"-Wl,-rpath,{d}" for d in libdirs])
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    lib = _build_lib(force, verbose)
+    build_ext(force, verbose)
+    return lib
+
+
+def _build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -1,6 +1,12 @@
 """Counterpart of the reference's pybind module ``diff_lidar_tracer._C``
-(DLT/ext.cpp:18-23): the same four names, argument orders and return tuples,
-implemented on liblrt_hip.so through ctypes.
+(DLT/ext.cpp:18-23): the same four names, argument orders and return tuples.
+
+Two bindings of the C ABI (include/lrt.h) live behind these names:
+  * ``_C_ext`` -- the PyTorch-ROCm C++ extension (csrc/lrt_torch_ext.cpp, pybind11: at::Tensor arguments, contiguity, output
+    allocation, current HIP stream and the dead zero outputs in C++), the DEFAULT whenever it has been built;
+  * ctypes on liblrt_hip.so (this file) -- the fallback and the binding INTEGRATION.md shows; ``LRT_TORCH_EXT=0`` forces it.
+``BACKEND`` names the one in use.  The management calls (options, statistics, timing, status checks) go through ctypes in
+both cases: they are not on the per-iteration path.
 
     OptiXStateWrapper(pkg_dir)                           DLT/optix_tracer/optix_wrapper.cpp:177-233
     build_acceleration_structure(state, vertices, triangles, rebuild)   DLT/trace_surfels.cpp:46-148
@@ -22,13 +28,89 @@ by the kernels; ``build_acceleration_structure`` marks the structure dirty and
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _capi
 
+_ext = None
+_ext_error = None
+if os.environ.get("LRT_TORCH_EXT", "1") != "0":
+    try:
+        _capi.load()                       # liblrt_hip.so first (after torch), so that the extension binds the same instance
+        from . import _C_ext as _ext       # built in-tree by lidar_rt_amd.build.build_ext
+    except Exception as ex:                # not built (or not loadable): the ctypes binding below serves the same surface
+        _ext, _ext_error = None, ex
+BACKEND = "torch-extension" if _ext is not None else "ctypes"
 
-class OptiXStateWrapper:
-    """Tracer state (LBVH buffers, workspace) bound to one device.  The name is
+
+class _StateAPI:
+    """What both state classes offer beyond the reference's opaque handle: options, statistics, timing, status checks
+    (management calls through ctypes; `handle(device)` -> (device index, lrt_state* as c_void_p))."""
+
+    def get_option(self, name: str, device=None) -> int:
+        """Current value of an option on `device` (hit_cap may have grown after an overflow of the hit record)."""
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _, h = self.handle(device)
+        v = C.c_int(0)
+        _capi.check(self._lib.lrt_get_option(h, name.encode(), C.byref(v)), "lrt_get_option")
+        return int(v.value)
+
+    def check(self, device=None, wait: bool = True):
+        """Raise if the most recent forward on `device` reported an internal overflow (waits for it when `wait`)."""
+        want = None
+        if device is not None:
+            dv = torch.device(device)
+            want = dv.index if dv.index is not None else torch.cuda.current_device()
+        for idx, h in self._all_handles().items():
+            if want is None or idx == want:
+                _capi.check(self._lib.lrt_check_forward(h, 1 if wait else 0), "lrt_forward")
+
+    def enable_stats(self, enable: bool = True):
+        self.stats_enabled = bool(enable)
+        for h in self._all_handles().values():
+            self._lib.lrt_enable_stats(h, 1 if enable else 0)
+
+    def built_count(self, device=None) -> int:
+        """Primitives in the current LBVH of `device` (fewer than P after a ray-cone culled build)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        return int(self._lib.lrt_built_count(h))
+
+    def get_stats(self, device=None):
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        arr = (C.c_uint64 * 8)()
+        with torch.cuda.device(idx):
+            s = torch.cuda.current_stream().cuda_stream
+            _capi.check(self._lib.lrt_get_stats(h, arr, C.c_void_p(s)), "lrt_get_stats")
+        names = ("candidates", "composited", "passes", "nodes_visited", "prims_tested", "tile_clk_sum", "tile_clk_max",
+                 "wave_inserts")
+        return {n: int(arr[i]) for i, n in enumerate(names)}
+
+    def enable_timing(self, enable: bool = True):
+        self.timing_enabled = bool(enable)
+        for h in self._all_handles().values():
+            self._lib.lrt_enable_timing(h, 1 if enable else 0)
+
+    def get_timing(self, device=None):
+        """HIP-event timings since the last call: {'build'|'fwd'|'bwd': (sum_ms, count)}."""
+        import ctypes as C
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx, h = self.handle(device)
+        ms = (C.c_double * 4)(); cnt = (C.c_int * 4)()
+        with torch.cuda.device(idx):
+            s = torch.cuda.current_stream().cuda_stream
+            _capi.check(self._lib.lrt_get_timing(h, ms, cnt, C.c_void_p(s)), "lrt_get_timing")
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(("build", "fwd", "bwd"))}
+
+
+
+class _CtypesState(_StateAPI):
+    """Tracer state (LBVH buffers, workspace) bound to one device, ctypes binding.  The exported name `OptiXStateWrapper` is
     kept for drop-in compatibility; nothing here uses OptiX."""
 
     def __init__(self, pkg_dir: str = ""):
@@ -42,6 +124,9 @@ class OptiXStateWrapper:
         self._since_full = {}; self._full_P = {}
         self.stats_enabled = False
         self.options = {}
+
+    def _all_handles(self):
+        return self._handles
 
     def handle(self, device: torch.device):
         if device.type != "cuda":
@@ -71,64 +156,6 @@ class OptiXStateWrapper:
         for h in self._handles.values():
             _capi.check(self._lib.lrt_set_option(h, name.encode(), int(value)), "lrt_set_option")
 
-    def get_option(self, name: str, device=None) -> int:
-        """Current value of an option on `device` (hit_cap may have grown after an overflow of the hit record)."""
-        import ctypes as C
-        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        _, h = self.handle(device)
-        v = C.c_int(0)
-        _capi.check(self._lib.lrt_get_option(h, name.encode(), C.byref(v)), "lrt_get_option")
-        return int(v.value)
-
-    def check(self, device=None, wait: bool = True):
-        """Raise if the most recent forward on `device` reported an internal overflow (waits for it when `wait`)."""
-        want = None
-        if device is not None:
-            dv = torch.device(device)
-            want = dv.index if dv.index is not None else torch.cuda.current_device()
-        for idx, h in self._handles.items():
-            if want is None or idx == want:
-                _capi.check(self._lib.lrt_check_forward(h, 1 if wait else 0), "lrt_forward")
-
-    def enable_stats(self, enable: bool = True):
-        self.stats_enabled = bool(enable)
-        for h in self._handles.values():
-            self._lib.lrt_enable_stats(h, 1 if enable else 0)
-
-    def built_count(self, device=None) -> int:
-        """Primitives in the current LBVH of `device` (fewer than P after a ray-cone culled build)."""
-        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        idx, h = self.handle(device)
-        return int(self._lib.lrt_built_count(h))
-
-    def get_stats(self, device=None):
-        import ctypes as C
-        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        idx, h = self.handle(device)
-        arr = (C.c_uint64 * 8)()
-        with torch.cuda.device(idx):
-            s = torch.cuda.current_stream().cuda_stream
-            _capi.check(self._lib.lrt_get_stats(h, arr, C.c_void_p(s)), "lrt_get_stats")
-        names = ("candidates", "composited", "passes", "nodes_visited", "prims_tested", "tile_clk_sum", "tile_clk_max",
-                 "wave_inserts")
-        return {n: int(arr[i]) for i, n in enumerate(names)}
-
-    def enable_timing(self, enable: bool = True):
-        self.timing_enabled = bool(enable)
-        for h in self._handles.values():
-            self._lib.lrt_enable_timing(h, 1 if enable else 0)
-
-    def get_timing(self, device=None):
-        """HIP-event timings since the last call: {'build'|'fwd'|'bwd': (sum_ms, count)}."""
-        import ctypes as C
-        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        idx, h = self.handle(device)
-        ms = (C.c_double * 4)(); cnt = (C.c_int * 4)()
-        with torch.cuda.device(idx):
-            s = torch.cuda.current_stream().cuda_stream
-            _capi.check(self._lib.lrt_get_timing(h, ms, cnt, C.c_void_p(s)), "lrt_get_timing")
-        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(("build", "fwd", "bwd"))}
-
     def __del__(self):
         try:
             for h in self._handles.values():
@@ -136,6 +163,30 @@ class OptiXStateWrapper:
             self._handles = {}
         except Exception:
             pass
+
+
+if _ext is not None:
+    class _ExtState(_ext.OptiXStateWrapper, _StateAPI):
+        """The extension's state object (C++ owns the per-device lrt_state handles) with the management helpers on top."""
+
+        def __init__(self, pkg_dir: str = ""):
+            _ext.OptiXStateWrapper.__init__(self, pkg_dir)
+            self._lib = _capi.load()
+
+        def _all_handles(self):
+            import ctypes as C
+            return {i: C.c_void_p(p) for i, p in self.handles().items()}
+
+        def handle(self, device: torch.device):
+            import ctypes as C
+            if device.type != "cuda":
+                raise RuntimeError("diff_lidar_tracer: tensors must be on a HIP (cuda) device; there is no CPU path")
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            return idx, C.c_void_p(self.handle_ptr(idx))
+
+    OptiXStateWrapper = _ExtState
+else:
+    OptiXStateWrapper = _CtypesState
 
 
 def _check_f32_cuda(t: torch.Tensor, name: str):
@@ -150,7 +201,7 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def build_acceleration_structure(state: OptiXStateWrapper, vertices: torch.Tensor, triangles: torch.Tensor,
+def _ct_build_acceleration_structure(state, vertices: torch.Tensor, triangles: torch.Tensor,
                                  rebuild: int = 1) -> None:
     # shape checks and messages of DLT/trace_surfels.cpp:53-58
     if vertices.ndimension() != 2 or vertices.size(1) != 3:
@@ -163,7 +214,7 @@ def build_acceleration_structure(state: OptiXStateWrapper, vertices: torch.Tenso
     state.handle(vertices.device)      # create the per-device state eagerly (errors surface here)
 
 
-def build_from_gaussians(state: OptiXStateWrapper, means3D, scales, rotations, opacities, scale_modifier=1.0, cull_rays=None):
+def _ct_build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier=1.0, cull_rays=None):
     """Fused fast path: LBVH straight from the Gaussian parameters (no vertices tensor).
 
     cull_rays = (ray_o, ray_d): build only what these rays can reach (lrt_build_for_rays; used by the azimuth-sharded
@@ -228,7 +279,7 @@ def _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opaciti
     return P
 
 
-def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertices, background, means3D, shs,
+def _ct_trace_surfels(state, training: bool, ray_o, ray_d, vertices, background, means3D, shs,
                   degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
                   transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool):
     P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
@@ -238,7 +289,7 @@ def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertic
     dev = means3D.device
     idx, h = state.handle(dev)
     if state._dirty.get(idx, True) or state._built_P.get(idx, -1) != P or state._built_mod.get(idx) != float(scale_modifier):
-        build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier)   # also when the scale modifier changed
+        _ct_build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier)   # also when the scale modifier changed
     ro, rd = ray_o.detach().contiguous(), ray_d.detach().contiguous()      # ray_o is an expanded view upstream
     bg = background.detach().contiguous()
     sh = shs.detach().contiguous()
@@ -253,7 +304,7 @@ def trace_surfels(state: OptiXStateWrapper, training: bool, ray_o, ray_d, vertic
     return out, out_i, accum
 
 
-def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, background, means3D, shs,
+def _ct_trace_surfels_backward(state, ray_o, ray_d, vertices, background, means3D, shs,
                            degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
                            transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
                            out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None):
@@ -305,3 +356,33 @@ def trace_surfels_backward(state: OptiXStateWrapper, ray_o, ray_d, vertices, bac
     d_trans = torch.zeros((P, 9), **opts)
     d_g3abs = torch.zeros((P, 3), **opts)
     return d_means, d_shs, d_colors, d_opac, d_scales, d_rot, d_trans, d_g3abs
+
+
+# ---- the four names of DLT/ext.cpp:18-23 (+ build_from_gaussians): the extension for its own state objects, ctypes otherwise
+def _is_ext(state) -> bool:
+    return _ext is not None and isinstance(state, _ext.OptiXStateWrapper)
+
+
+def build_acceleration_structure(state, vertices: torch.Tensor, triangles: torch.Tensor, rebuild: int = 1) -> None:
+    return (_ext.build_acceleration_structure if _is_ext(state) else _ct_build_acceleration_structure)(state, vertices, triangles, rebuild)
+
+
+def build_from_gaussians(state, means3D, scales, rotations, opacities, scale_modifier=1.0, cull_rays=None):
+    return (_ext.build_from_gaussians if _is_ext(state) else _ct_build_from_gaussians)(state, means3D, scales, rotations, opacities,
+                                                                                      scale_modifier, cull_rays=cull_rays)
+
+
+def trace_surfels(state, training: bool, ray_o, ray_d, vertices, background, means3D, shs, degree: int, colors_precomp, opacities,
+                  scales, scale_modifier: float, rotations, transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool):
+    return (_ext.trace_surfels if _is_ext(state) else _ct_trace_surfels)(state, training, ray_o, ray_d, vertices, background, means3D, shs, degree,
+                                                                         colors_precomp, opacities, scales, scale_modifier, rotations, transMat_precomp,
+                                                                         viewmatrix, projmatrix, campos, prefiltered, debug)
+
+
+def trace_surfels_backward(state, ray_o, ray_d, vertices, background, means3D, shs, degree: int, colors_precomp, opacities, scales,
+                           scale_modifier: float, rotations, transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None):
+    return (_ext.trace_surfels_backward if _is_ext(state) else _ct_trace_surfels_backward)(
+        state, ray_o, ray_d, vertices, background, means3D, shs, degree, colors_precomp, opacities, scales, scale_modifier, rotations,
+        transMat_precomp, viewmatrix, projmatrix, campos, prefiltered, debug, out_attr_float32, out_attr_uint32, dL_dout_attr_float32,
+        grads_out=grads_out, forward_serial=forward_serial)

@@ -113,3 +113,35 @@ def test_simple_knn_surface_matches_reference(lib):
         distCUDA2(torch.zeros(5, 3))
     assert lib.lrt_knn_mean_dist2(None, 4, None, None, None) != 0
     assert b"null state" in lib.lrt_last_error()
+
+
+def test_both_bindings_of_the_pybind_surface(lib):
+    """The torch C++ extension (`_C_ext`, the default) and the ctypes binding expose the reference's `_C` names with the same
+    behaviour at the boundary: state object, shape-error messages (DLT/trace_surfels.cpp:53-58, :178-180), the refusal of the dead
+    precomputed inputs, CPU tensors rejected; `LRT_TORCH_EXT=0` selects the fallback."""
+    import subprocess, sys
+    from lidar_rt_amd.diff_lidar_tracer import _C
+    assert _C.BACKEND == "torch-extension", f"the extension must be built and importable: {_C._ext_error!r}"
+    assert os.path.exists(lrt_build.ext_path()) and not lrt_build.ext_is_stale()
+    code = (
+        "import torch, pytest\n"
+        "from lidar_rt_amd.diff_lidar_tracer import _C\n"
+        "st = _C.OptiXStateWrapper('')\n"
+        "st.set_option('hit_cap', 128); assert dict(st.options)['hit_cap'] == 128\n"
+        "st.refit_interval = 3; assert st.refit_interval == 3\n"
+        "with pytest.raises(RuntimeError, match='vertices must have dimensions'):\n"
+        "    _C.build_acceleration_structure(st, torch.zeros(3), torch.zeros(2, 3, dtype=torch.int32), 1)\n"
+        "with pytest.raises(RuntimeError, match='triangles must have dimensions'):\n"
+        "    _C.build_acceleration_structure(st, torch.zeros(3, 3), torch.zeros(2, dtype=torch.int32), 1)\n"
+        "e = torch.empty(0); z = torch.zeros\n"
+        "with pytest.raises(RuntimeError, match='means3D must have dimensions'):\n"
+        "    _C.trace_surfels(st, True, z(2, 2, 3), z(2, 2, 3), e, z(3), z(4), z(4, 16, 3), 3, e, z(4, 1), z(4, 2), 1.0, z(4, 4), e, e, e, e, False, False)\n"
+        "with pytest.raises(RuntimeError, match='CUDA|HIP|cuda'):\n"
+        "    _C.trace_surfels(st, True, z(2, 2, 3), z(2, 2, 3), e, z(3), z(4, 3), z(4, 16, 3), 3, e, z(4, 1), z(4, 2), 1.0, z(4, 4), e, e, e, e, False, False)\n"
+        "with pytest.raises(RuntimeError, match='CUDA|HIP|cuda'):\n"
+        "    _C.build_from_gaussians(st, z(4, 3), z(4, 2), z(4, 4), z(4, 1))\n"
+        "print(_C.BACKEND)\n")
+    for env_val, want in (("1", "torch-extension"), ("0", "ctypes")):
+        out = subprocess.run([sys.executable, "-c", code], check=True, cwd=REPO, env=dict(os.environ, LRT_TORCH_EXT=env_val),
+                             capture_output=True, text=True, timeout=300).stdout
+        assert out.strip().splitlines()[-1] == want

@@ -576,3 +576,31 @@ def test_speculative_culled_build_reports_lost_primitives():
         frame()
     np.testing.assert_array_equal(frame(), ref)                                # reads the count back again
     np.testing.assert_array_equal(frame(), ref)
+
+
+def test_ctypes_binding_gives_the_results_of_the_torch_extension(s10k, tmp_path):
+    """`_C` runs on the torch C++ extension by default; `LRT_TORCH_EXT=0` selects the ctypes binding of the same C ABI.  Same
+    inputs, same kernels: the image is bit-identical, the gradients agree to the backward's run-to-run noise."""
+    import subprocess, sys
+    from lidar_rt_amd.diff_lidar_tracer import _C
+    assert _C.BACKEND == "torch-extension", _C._ext_error
+    sc, o, d, dL = s10k
+    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    np.savez(str(tmp_path / "in.npz"), o=o, d=d, dL=dL, **sc)
+    code = ("import sys, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from lidar_rt_amd.diff_lidar_tracer import _C\n"
+            "assert _C.BACKEND == 'ctypes'\n"
+            "from lidar_rt_amd import scenes\n"
+            "from tests.hip_util import run_hip\n"
+            "z = np.load(%r)\n"
+            "sc = {k: z[k] for k in ('means', 'scales', 'rotations', 'opacities', 'shs')}\n"
+            "r = run_hip(sc, z['o'], z['d'], 3, scenes.BG_DEFAULT, z['dL'])\n"
+            "np.savez(%r, out=r['out'], accum=r['accum'], **{'g_' + k: v for k, v in r['grads'].items()})\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LRT_TORCH_EXT="0"), timeout=600,
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    b = np.load(str(tmp_path / "out.npz"))
+    np.testing.assert_array_equal(a["out"], b["out"])
+    for k in GRADS:
+        assert rel_l2(a["grads"][k], b["g_" + k]) < 1e-5, k
