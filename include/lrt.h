@@ -62,8 +62,10 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
 
 /* The same build for a tracer that will only see the given rays (one rank's azimuth slab of a sharded frame; not in the
  * reference): Gaussians whose bounding sphere lies outside the cone around the rays are left out of the LBVH (conservative:
- * results are unchanged).  ray_o, ray_d (n_rays,3).  Costs one 4-byte device->host read-back (the sort and the tree are sized
- * by the kept count); cones wider than ~80 degrees keep everything. */
+ * results are unchanged).  ray_o, ray_d (n_rays,3).  The sort and the tree are sized by the kept count: the FIRST culled build of a
+ * given P reads it back (one 8-byte device->host copy, a host wait); later ones are sized speculatively from the previous build's
+ * count (x 1.25 + 4096) without a wait, and primitives that did not fit raise error bit 8 in the next forward (option spec_cull=0
+ * restores the read-back).  Cones wider than ~80 degrees keep everything. */
 int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
                        const float* opacities, float scale_modifier, int n_rays, const float* ray_o, const float* ray_d,
                        void* stream);

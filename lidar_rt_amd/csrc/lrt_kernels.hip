@@ -889,7 +889,8 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         unsigned* bnext = st->bounds + 6 * ((st->bounds_sel + 1) & 1);
         st->bounds_sel ^= 1;
         int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
-        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)cone);
+        // bounds of ALL valid Gaussians, also for a culled build: the Morton grid is that of the full build and the pass needs no cone test
+        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
         float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
         // The sort and the tree of a culled build are sized by the kept count.  Reading it back stalls the launch queue (the
         // host cannot run ahead), so from the second culled build of the same P on the size is SPECULATIVE: 1.25 x the previous

@@ -4,8 +4,8 @@
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI;
 "gloo" on CPU for the tests).  Every rank holds the full Gaussian set; rank r
 traces the contiguous column slab ``[r*W/N, (r+1)*W/N)`` of the (H, W) range
-image.  From 8 ranks on a rank's LBVH holds only the Gaussians its slab's ray
-cone can reach (``lrt_build_for_rays``; below that the cull costs more than it saves).
+image.  From 4 ranks on a rank's LBVH holds only the Gaussians its slab's ray
+cone can reach (``lrt_build_for_rays``; below that there is no useful cone).
 
 * forward : local slab -> ONE ``all_gather`` of ``[status | (H, W/N, 9) slab]``
   (4.7 MB at 64x2048) so every rank sees the whole image for image-space losses
@@ -139,10 +139,10 @@ class ShardedTracer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # build the LBVH for this rank's rays only (lrt_build_for_rays): Gaussians outside the cone around the slab's rays are left
         # out.  The library sizes the sort and the tree from the previous frame's kept count, so no read-back stalls the launch
-        # queue.  Measured on S1M (tools/slab_timing.py, profiles/r02_summary.md): the cull passes cost more than the smaller sort
-        # saves up to 4 ranks (N=4: build 0.27 -> 0.32 ms with a quarter of the Gaussians kept), and pay from 8 ranks on
-        # (0.27 -> 0.20-0.25 ms, an eighth kept); a 180-degree slab (N=2) has no useful cone at all.  Hence: on from 8 ranks.
-        self.cull_build = self.world >= 8
+        # queue.  Measured on S1M (tools/slab_timing.py, CULL=1, profiles/r03_summary.md): with the division-free cone test of round 3
+        # the culled build is ahead from 4 ranks on (N=4: 0.265 -> 0.238 ms with a quarter of the Gaussians kept, N=8: 0.262 -> 0.182 ms
+        # with an eighth); what is left is a chain of ~16 small launches.  A 180-degree slab (N=2) has no useful cone; 3 ranks: 120 degrees, none either.
+        self.cull_build = self.world >= 4
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
         if self.world > 1 and hasattr(self.backend, "defer_errors"):
