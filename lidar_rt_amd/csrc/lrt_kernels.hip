@@ -69,8 +69,8 @@ struct lrt_state {
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
     float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
-    unsigned* bounds;    // 2 x 6 ordered-uint (min xyz, max xyz), used alternately
-    int bounds_sel;
+    unsigned* bounds;    // 3 x 6 ordered-uint (min xyz, max xyz): read by this build / accumulated for the next / armed for the one after
+    int bounds_sel, bounds_ready, lag_bounds;
     int order_P;        // vals_b holds the sorted order of an unculled build of this many primitives (lrt_refit), else -1
     unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
     // speculative sizing of the culled build: the sort and the tree are sized from the PREVIOUS culled build's kept count
@@ -507,8 +507,9 @@ lrt_state* lrt_create(int device)
     st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
     for (int i = 0; i < 8; i++) st->hit_ovf_host[i] = 0;
     st->spec_bwd = 1; st->spec_margin = 65536;
-    const unsigned bounds_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    if (hipMalloc(&st->bounds, 12 * sizeof(unsigned)) != hipSuccess || hipMemcpy(st->bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice) != hipSuccess ||
+    const unsigned bounds_init[18] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    st->lag_bounds = 1;
+    if (hipMalloc(&st->bounds, 18 * sizeof(unsigned)) != hipSuccess || hipMemcpy(st->bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&st->stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(st->stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "lrt_create: hipMalloc failed");
@@ -569,6 +570,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
     if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
     if (!strcmp(name, "cull_guess")) { st->cull_guess = value; return LRT_OK; }   // test hook: speculative size of the NEXT culled build
+    if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
@@ -885,12 +887,19 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
             hipLaunchKernelGGL(k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
         }
-        unsigned* bcur = st->bounds + 6 * (st->bounds_sel & 1);    // two sets: k_morton re-arms the other one for the next build
-        unsigned* bnext = st->bounds + 6 * ((st->bounds_sel + 1) & 1);
-        st->bounds_sel ^= 1;
-        int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;          // few blocks: the 6 atomics per block hit the same words
-        // bounds of ALL valid Gaussians, also for a culled build: the Morton grid is that of the full build and the pass needs no cone test
-        hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
+        // three bounds sets rotate: this build READS set s (the box of the previous build's centres -- or, on the first build of a state
+        // and with option lag_bounds=0, the box k_bounds computes now), ACCUMULATES its own frame's box into set s+1 and ARMS set s+2
+        unsigned* bcur = st->bounds + 6 * (st->bounds_sel % 3);
+        unsigned* bacc = st->bounds + 6 * ((st->bounds_sel + 1) % 3);
+        unsigned* barm = st->bounds + 6 * ((st->bounds_sel + 2) % 3);
+        st->bounds_sel = (st->bounds_sel + 1) % 3;
+        if (!st->bounds_ready || !st->lag_bounds) {
+            const unsigned init6[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+            if (st->bounds_ready) HIPCHK(hipMemcpyAsync(bcur, init6, sizeof(init6), hipMemcpyHostToDevice, stream));   // lag_bounds=0: discard the carried box
+            int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;      // few blocks: the 6 atomics per block hit the same words
+            hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
+        }
+        st->bounds_ready = 1;
         float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
         // The sort and the tree of a culled build are sized by the kept count.  Reading it back stalls the launch queue (the
         // host cannot run ahead), so from the second culled build of the same P on the size is SPECULATIVE: 1.25 x the previous
@@ -905,8 +914,9 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             st->cull_guess = 0;
         }
         if (spec) HIPCHK(hipMemsetAsync(st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
-        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, cone, keep_cap);
-        else hipLaunchKernelGGL(k_morton, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, opac, bcur, bnext, st->keys_a, st->vals_a, scales, rots, pack);
+        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap);
+        else { int mb = (P + TB - 1) / TB; if (mb > 1024) mb = 1024;
+               hipLaunchKernelGGL(k_morton, dim3(mb), dim3(TB), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack); }
         if (cone) {
             HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             st->cone_prev_P = P;
