@@ -101,6 +101,24 @@ class Oracle:
             res["n_cand"] = nc; res["n_comp"] = nk
         return res
 
+    def forward_trace(self, ray_o, ray_d, shs, sh_degree: int, bg, cap: int = 160) -> Dict[str, np.ndarray]:
+        """The forward with a per-ray EVENT TRACE (tools/parity_events.py): every candidate in the order the raygen loop looks at it:
+        n (H,W), g / t / alpha (un-clamped) / flags (H,W,cap); flags: 1 composited, 2 skipped (alpha < 1/255), 4 stopped the ray,
+        8 first candidate after a restart."""
+        t = self.np_t
+        ray_o = np.ascontiguousarray(ray_o, t); ray_d = np.ascontiguousarray(ray_d, t)
+        H, W = ray_o.shape[:2]
+        shs = np.ascontiguousarray(shs, t).reshape(self.P, -1, 3)
+        bg = np.ascontiguousarray(bg, t).reshape(3)
+        out = np.zeros((H, W, 9), t)
+        n = np.zeros((H, W), np.int32); g = np.zeros((H, W, cap), np.int32)
+        tt = np.zeros((H, W, cap), t); aa = np.zeros((H, W, cap), t); ff = np.zeros((H, W, cap), np.uint8)
+        getattr(lib(), f"orc_forward_trace_{self.sfx}")(
+            self._h, C.c_int(H), C.c_int(W), _p(ray_o), _p(ray_d), C.c_int(shs.shape[1]), C.c_int(sh_degree),
+            _p(shs), _p(self.means), _p(self.scales), _p(self.rot), _p(self.opac),
+            self.c_t(self.mod), _p(bg), _p(out), C.c_int(cap), _p(n), _p(g), _p(tt), _p(aa), _p(ff))
+        return {"out": out, "n": n, "g": g, "t": tt, "alpha": aa, "flags": ff}
+
     def backward(self, ray_o, ray_d, shs, sh_degree: int, bg, out, dL_dout) -> Dict[str, np.ndarray]:
         t = self.np_t
         ray_o = np.ascontiguousarray(ray_o, t); ray_d = np.ascontiguousarray(ray_d, t)
