@@ -68,7 +68,7 @@ struct lrt_state {
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
-    float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
+    float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack, pack_valid, refine_ties;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 3 x 6 ordered-uint (min xyz, max xyz): read by this build / accumulated for the next / armed for the one after
     int bounds_sel, bounds_ready, lag_bounds;
     int order_P;        // vals_b holds the sorted order of an unculled build of this many primitives (lrt_refit), else -1
@@ -151,6 +151,7 @@ struct TraceParams {
     int* near_list; unsigned* near_count;
     unsigned root_first, root_count;   // k_fwd_cr4: the nodes its walk starts from (a whole level of the tree)
     unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
+    const float4* pack;    // k_fwd_cr4: the build's packed raw parameters (fp64 re-evaluation of depths closer than 2 ulp), or null
 };
 
 
@@ -506,7 +507,7 @@ lrt_state* lrt_create(int device)
     st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9;
     st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
     for (int i = 0; i < 8; i++) st->hit_ovf_host[i] = 0;
-    st->spec_bwd = 1; st->spec_margin = 65536;
+    st->spec_bwd = 1; st->spec_margin = 65536; st->refine_ties = 1;
     const unsigned bounds_init[18] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     st->lag_bounds = 1;
     if (hipMalloc(&st->bounds, 18 * sizeof(unsigned)) != hipSuccess || hipMemcpy(st->bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice) != hipSuccess ||
@@ -570,6 +571,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
     if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
     if (!strcmp(name, "cull_guess")) { st->cull_guess = value; return LRT_OK; }   // test hook: speculative size of the NEXT culled build
+    if (!strcmp(name, "refine_ties")) { st->refine_ties = value ? 1 : 0; return LRT_OK; }   // 1 (default): hits closer than 2 ulp of t are ordered by their fp64 depth (needs the packed parameter lines of an unculled build); 0: by (t, gidx)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
@@ -914,7 +916,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             st->cull_guess = 0;
         }
         if (spec) HIPCHK(hipMemsetAsync(st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
-        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap);
+        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
         else { int mb = (P + TB - 1) / TB; if (mb > 1024) mb = 1024;
                hipLaunchKernelGGL(k_morton, dim3(mb), dim3(TB), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack); }
         if (cone) {
@@ -958,6 +960,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
     st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
+    st->pack_valid = (P > 0 && !st->no_pack) ? 1 : 0;     // k_morton / k_morton_cull wrote the packed lines of every primitive that can be hit
     st->order_P = (n_rays == 0 && P > 0) ? P : -1;
     return LRT_OK;
 }
@@ -990,6 +993,7 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
         hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     HIPCHK(hipGetLastError());
     st->mod = mod;
+    st->pack_valid = pack ? 1 : 0;
     return LRT_OK;
 }
 
@@ -1114,6 +1118,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
         tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
         tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag; tp.c4_qlimit = (unsigned)st->c4_qlimit;
+        tp.pack = (st->pack_valid && st->refine_ties) ? st->pack : nullptr;
         {   // start level of the walk: the highest level with at most `root_nodes` nodes (option; 1 = the root itself)
             int nl_, L_, cnt_[LRT_MAX_LEVELS], off_[LRT_MAX_LEVELS];
             tree_layout(st->P_built > 0 ? st->P_built : 1, &nl_, &L_, cnt_, off_);
@@ -1157,19 +1162,20 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             }
             if (getenv("LRT_DEBUG_OCC")) {
                 int n0 = -1, n1 = -1, n2 = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<true, 4>, 256, 0);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true, 8>, 512, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_fwd_cr4<true, 4, false>, 256, 0);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_fwd_cr4<true, 8, false>, 512, 0);
                 fprintf(stderr, "[lrt] occupancy blocks/CU: k_fwd_cr4<true,4> %d, k_fwd_cr4<true,8> %d, k_fwd_cr<true> %d; launching %d blocks of %d waves\n", n0, n1, n2, blocks, nw);
             }
             ScopedTimer tm(st, 1, stream);
             const float* rec_ = (const float*)st->rec; const float* naos_ = (const float*)st->nodes_aos;
             const bool dfr = defer && record;
-            if (wg4 && nw == 8) {
-                if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
-                else hipLaunchKernelGGL((k_fwd_cr4<false, 8>), dim3(blocks), dim3(512), 0, stream, tp, rec_, naos_);
-            } else {
-                if (dfr) hipLaunchKernelGGL((k_fwd_cr4<true, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
-                else hipLaunchKernelGGL((k_fwd_cr4<false, 4>), dim3(blocks), dim3(256), 0, stream, tp, rec_, naos_);
+            {   // the STATS instantiations only when counters or the per-tile profile are asked for
+                const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
+                const dim3 g_(blocks), b_(64 * nw);
+#define LRT_CR4(D_, N_, S_) hipLaunchKernelGGL((k_fwd_cr4<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
+                if (wg4 && nw == 8) { if (dfr) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); } else { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); } }
+                else                { if (dfr) { if (sts) LRT_CR4(true, 4, true); else LRT_CR4(true, 4, false); } else { if (sts) LRT_CR4(false, 4, true); else LRT_CR4(false, 4, false); } }
+#undef LRT_CR4
             }
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
             hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);

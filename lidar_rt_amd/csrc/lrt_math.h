@@ -244,6 +244,22 @@ LRT_HD void lrt_hit_backward(const LrtHitGeom* h, const float* o, const float* d
     g->d_rot[3] = 2.f * (x * (dR0[2] + dR2[0]) + y * (dR1[2] + dR2[1]) - 2.f * z * (dR0[0] + dR1[1]) + w * (dR0[1] - dR1[0]));
 }
 
+// Hit distance of the ray (o, d) on the plane of Gaussian g in fp64, from the RAW fp32 parameters as the build packed them
+// ((mean, opacity) (scale, rot.wx) (rot.yz, -, -) per primitive): n = third column of R(q / |q|) (lrt_quat_to_R), t = n.(mu - o) / n.d.
+// Used to order hits that fp32 cannot separate (closer than 2 ulp).
+#if defined(__HIPCC__)
+__device__ __forceinline__ double lrt_t_exact(const float4* __restrict__ pack, int g, const float* o, const float* d)
+{
+    const float4 a = pack[4 * (size_t)g], b = pack[4 * (size_t)g + 1], c = pack[4 * (size_t)g + 2];
+    double w = b.z, x = b.w, y = c.x, z = c.y;
+    const double s = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+    w *= s; x *= s; y *= s; z *= s;
+    const double n0 = 2.0 * (x * z + w * y), n1 = 2.0 * (y * z - w * x), n2 = 1.0 - 2.0 * (x * x + y * y);
+    const double c0 = (double)a.x - (double)o[0], c1 = (double)a.y - (double)o[1], c2 = (double)a.z - (double)o[2];
+    return (n0 * c0 + n1 * c1 + n2 * c2) / (n0 * (double)d[0] + n1 * (double)d[1] + n2 * (double)d[2]);
+}
+#endif
+
 // 63-bit Morton code from three 21-bit cell coordinates.
 LRT_HD uint64_t lrt_expand21(uint64_t v)
 {
