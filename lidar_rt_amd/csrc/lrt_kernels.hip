@@ -1133,7 +1133,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             // long as its heaviest tile), else 4
             const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 6 ? 8 : 4));
             const int per_cu = nw == 8 ? (st->wg4_per_cu + 1) / 2 : st->wg4_per_cu;
-            if (wg4 && tp.c4_qlimit < 32u * (unsigned)nw + 8u) tp.c4_qlimit = 32u * (unsigned)nw + 8u;   // room for one round's appends
+            if (wg4 && tp.c4_qlimit < 64u * (unsigned)nw + 8u) tp.c4_qlimit = 64u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
             int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;
             if (blocks > st->cr_blocks_cap) {
