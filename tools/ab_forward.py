@@ -28,7 +28,7 @@ reps = int(os.environ.get("LRT_AB_REPS", "30"))
 with_bwd = os.environ.get("LRT_AB_BWD", "0") == "1"
 ref = None
 be = HipBackend()
-DEFAULTS = {"fwd_mode": 2, "wg4_per_cu": 4, "c4_waves": 0, "root_nodes": 8, "slab0_mm": 24000, "learn_slab": 1}
+DEFAULTS = {"fwd_mode": 2, "wg4_per_cu": 4, "c4_waves": 0, "root_nodes": 32, "slab0_mm": 100000, "learn_slab": 1}
 for spec in (sys.argv[1:] or ["fwd_mode=2", "fwd_mode=3"]):
     opts = dict(DEFAULTS)
     for kv in spec.split(","):
