@@ -90,6 +90,7 @@ struct lrt_state {
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled; int hit_cap_auto; int key_avg, key_avg_alloc;   // key_avg: dense (gidx, id) key list sized for this many composited hits per ray
     unsigned long long *hit_keys, *hit_keys_sorted; unsigned* hit_count; unsigned key_cap; float4 *hit_pk, *ray_pk; unsigned* hit_off; void* scan_tmp; size_t scan_tmp_bytes; float2* hit_wa; int defer_colour; int fast_valid;
+    uint4* brec; uint4* brec2; unsigned* bk_g; unsigned* bk_M; unsigned* bk_small; size_t brec_cap, bk_M_words, bk_small_words;   // bucketed backward (bwd_mode 3): records, count matrix, per-bucket tables + work list
     void* bsort_tmp; size_t bsort_tmp_bytes; int bwd_mode; int reduce_mode;   // reduce_mode 2 = lane per hit + LDS-transposed column sums (default), 1 = lane per hit + DPP segmented scan, 0 = thread per 16 hits
     long long fwd_serial; // incremented by every lrt_forward: identifies which forward the hit record belongs to
     // stream-ordered backward: when the forward's status words have not reached the host yet, the backward is enqueued with sizes
@@ -152,6 +153,13 @@ struct TraceParams {
     unsigned root_first, root_count;   // k_fwd_cr4: the nodes its walk starts from (a whole level of the tree)
     unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
     const float4* pack;    // k_fwd_cr4: the build's packed raw parameters (fp64 re-evaluation of depths closer than 2 ulp), or null
+    // bucketed backward (lrt_bucket.inc): Gaussians in buckets of 2^bk_shift consecutive indices, rays in bk_ng groups of bk_rpg
+    uint4* brec; unsigned rec_cap;         // per-hit records (ray << bk_shift | g % 2^bk_shift, t, dL/dalpha, +-w), grouped by bucket
+    unsigned* bk_M;                        // [bk_ng][bk_nb] hits of a ray group per bucket -> exclusive prefix over the groups
+    unsigned* bk_tot;                      // [bk_nb] hits per bucket
+    unsigned* bk_base;                     // [bk_nb + 1] first record of a bucket
+    uint4* brec2; unsigned* bkg;          // the records in Gaussian order (ray, t, dL/dalpha, +-w) and their Gaussian
+    int bk_shift, bk_nb, bk_ng, bk_rpg;
 };
 
 
@@ -290,6 +298,7 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
 }
 
 #include "lrt_backward.inc"
+#include "lrt_bucket.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Sparse gradient exchange helpers (azimuth-sharded backward): row r <-> Gaussian idx[r], see include/lrt.h.
@@ -495,7 +504,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 2; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -529,7 +538,7 @@ void lrt_destroy(lrt_state* st)
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
-    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk);
+    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk); (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
     (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); rs_free(st->sort_build); rs_free(st->sort_bwd);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
@@ -587,8 +596,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "defer_colour")) { st->defer_colour = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
     if (!strcmp(name, "reduce_mode")) { if (value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: reduce_mode 0 and 1 were retired (k_bwd_reduce3 = mode 2 is the reduction)"); return LRT_OK; }
-    if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction
-        if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1 or 2");
+    if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction, 3 replay + bucketed reduction
+        if (value < 0 || value > 3) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1, 2 or 3");
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
     }
     if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
@@ -658,7 +667,7 @@ static int absorb_status(lrt_state* st)
         // a ray composited more hits than the record holds (that frame's backward re-traces): the following frames record with twice
         // the capacity; more hits than the dense key list holds: a longer key list
         if (st->hit_ovf_host[0] != 0 && st->hit_cap_auto && st->hit_cap < 4096 && st->pend_hw * (size_t)st->hit_cap * 2 < (1ull << 32)) st->hit_cap *= 2;
-        if (st->bwd_mode == 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;
+        if (st->bwd_mode >= 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;
     }
     return st->hit_ovf_host[4] | st->hit_ovf_host[2];
 }
@@ -1217,8 +1226,11 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
         LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null parameter/gradient pointer");
     DeviceGuard dg(st->device);
     hipStream_t stream = (hipStream_t)stream_;
-    if (P > 0) {   // trace_surfels.cpp:322-329: gradients start from zero
-        // adjacent buffers (the Python binding and the sharded path hand over views of one flat tensor) are filled at once
+    // trace_surfels.cpp:322-329: gradients start from zero.  Every path but the bucketed reduction (which stores all rows whole) adds
+    // into the tensors, so they are cleared first; adjacent buffers (the Python binding and the sharded path hand over views of one
+    // flat tensor) are filled at once
+    auto zero_grads = [&]() -> int {
+        if (P <= 0) return LRT_OK;
         struct Seg { float* p; size_t n; } seg[5] = {{d_means, (size_t)P * 3}, {d_shs, (size_t)P * M * 3}, {d_opac, (size_t)P},
                                                       {d_scales, (size_t)P * 2}, {d_rots, (size_t)P * 4}};
         for (int i = 1; i < 5; i++) for (int j = i; j > 0 && seg[j].p < seg[j - 1].p; j--) { Seg t = seg[j]; seg[j] = seg[j - 1]; seg[j - 1] = t; }
@@ -1228,7 +1240,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             if (n) HIPCHK(hipMemsetAsync(b, 0, n * sizeof(float), stream));
             i = j;
         }
-    }
+        return LRT_OK;
+    };
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg;
@@ -1243,7 +1256,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
         // the re-tracing fallback (enqueued behind it, returns at once when not needed).  Only the first backward of an image size
         // waits for the forward.
         bool ready = hipEventQuery(st->hit_ev) == hipSuccess;
-        const bool can_spec = st->spec_bwd && st->bwd_mode == 2 && st->est_valid && st->est_hw == (size_t)H * W && st->hit_keys;
+        const bool can_spec = st->spec_bwd && st->bwd_mode >= 2 && st->est_valid && st->est_hw == (size_t)H * W && st->hit_keys;
         if (!ready && !can_spec) { HIPCHK(hipEventSynchronize(st->hit_ev)); ready = true; }
         unsigned n_hits = 0; bool record_ok = true, spec = false;
         st->last_bwd_spec = ready ? 0 : 1;
@@ -1261,7 +1274,61 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             tp.n_tiles = tp.tiles_x * tp.tiles_y; tp.nsh = (deg + 1) * (deg + 1);
             tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
             tp.hw = H * W; tp.hit_ovf = st->hit_ovf;
-            const bool sorted = (st->bwd_mode == 2) && st->hit_keys && n_hits <= st->key_cap;
+            const bool sorted = (st->bwd_mode >= 2) && st->hit_keys && n_hits <= st->key_cap;
+            // bucketed reduction (bwd_mode 3): buckets of 2^shift consecutive Gaussian indices, about 4096 of them; the ray index and
+            // the index inside the bucket share one 32-bit word of the hit's record
+            int bk_shift = 5; long long bk_nb = 0;
+            if (st->bwd_mode == 3 && sorted && P > 0) {
+                while (bk_shift < 8 && ((long long)P >> bk_shift) > 4096) bk_shift++;
+                if ((((long long)P + (1 << bk_shift) - 1) >> bk_shift) > BK_MAX_NB) bk_shift = 9;
+                bk_nb = ((long long)P + (1 << bk_shift) - 1) >> bk_shift;
+            }
+            const bool bucket = bk_nb > 0 && bk_nb <= BK_MAX_NB && ((unsigned long long)H * W) < (1ull << (32 - bk_shift)) && tp.n_tiles > 0 && (spec || n_hits > 0);
+            if (!bucket) { rc = zero_grads(); if (rc) return rc; }
+            if (bucket) {
+                ScopedTimer tm(st, 2, stream);
+                const int hw = H * W;
+                const int rpg = hw <= 16 * BK_MAX_NG ? 16 : (hw + BK_MAX_NG - 1) / BK_MAX_NG;
+                const int ng = (hw + rpg - 1) / rpg;
+                const size_t m_words = (size_t)ng * bk_nb, small_words = (size_t)bk_nb * 2 + 2;
+                if (st->key_cap > st->brec_cap || m_words > st->bk_M_words || small_words > st->bk_small_words) {
+                    HIPCHK(hipStreamSynchronize(stream));
+                    (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
+                    st->brec = st->brec2 = nullptr; st->bk_g = nullptr; st->bk_M = nullptr; st->bk_small = nullptr; st->brec_cap = st->bk_M_words = st->bk_small_words = 0;
+                    HIPCHK(hipMalloc(&st->brec, (size_t)st->key_cap * sizeof(uint4)));
+                    HIPCHK(hipMalloc(&st->brec2, (size_t)st->key_cap * sizeof(uint4)));
+                    HIPCHK(hipMalloc(&st->bk_g, (size_t)st->key_cap * sizeof(unsigned)));
+                    HIPCHK(hipMalloc(&st->bk_M, m_words * sizeof(unsigned)));
+                    HIPCHK(hipMalloc(&st->bk_small, small_words * sizeof(unsigned)));
+                    st->brec_cap = st->key_cap; st->bk_M_words = m_words; st->bk_small_words = small_words;
+                }
+                tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk; tp.hit_wa = st->hit_wa;
+                tp.brec = st->brec; tp.brec2 = st->brec2; tp.bkg = st->bk_g; tp.rec_cap = st->key_cap; tp.bk_M = st->bk_M;
+                tp.bk_tot = st->bk_small; tp.bk_base = st->bk_small + bk_nb;
+                tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg;
+                if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
+                const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
+                tp.fast_prep = st->fast_valid;
+                if (lds_nb > 48 * 1024) {
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+                    if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+                    else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+                }
+                hipLaunchKernelGGL(k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
+                hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64)), dim3(1024), 0, stream, tp);
+                hipLaunchKernelGGL(k_bk_base, dim3(1), dim3(1024), 0, stream, tp);
+                if (tp.fast_prep) hipLaunchKernelGGL((k_bwd_prep<true, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
+                else hipLaunchKernelGGL((k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
+                hipLaunchKernelGGL(k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
+                hipLaunchKernelGGL(k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
+                if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise; k_bk_sort left rows of zeros)
+                    tp.guard = 2;
+                    HIPCHK(hipGetLastError());
+                    return launch_trace(st, tp, true, stream);
+                }
+                HIPCHK(hipGetLastError());
+                return LRT_OK;
+            }
             if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
                 hipLaunchKernelGGL(k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
@@ -1278,8 +1345,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
                     tp.fast_prep = st->fast_valid;
-                    if (tp.fast_prep) { hipLaunchKernelGGL(k_bwd_prep<true>, dim3(blocks), dim3(64), 0, stream, tp); st->fast_valid = 0; }   // hit_pk's colours are now overwritten: a second backward recomputes them
-                    else hipLaunchKernelGGL(k_bwd_prep<false>, dim3(blocks), dim3(64), 0, stream, tp);
+                    if (tp.fast_prep) { hipLaunchKernelGGL((k_bwd_prep<true, false>), dim3(blocks), dim3(64), 0, stream, tp); st->fast_valid = 0; }   // hit_pk's colours are now overwritten: a second backward recomputes them
+                    else hipLaunchKernelGGL((k_bwd_prep<false, false>), dim3(blocks), dim3(64), 0, stream, tp);
                 }
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
@@ -1311,6 +1378,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
         // a ray composited more hits than the record holds: this frame is re-traced (an order of magnitude slower); absorb_status
         // has doubled the capacity for the following ones
     }
+    rc = zero_grads(); if (rc) return rc;
     return launch_trace(st, tp, true, stream);   // no (complete) record: re-trace like the reference
 }
 
