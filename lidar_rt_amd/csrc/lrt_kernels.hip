@@ -1189,7 +1189,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
             hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
             if (dfr) {
-                const int cb = (int)HW < 256 * 32 ? (int)HW : 256 * 32;
+                const int cb = (int)HW < 256 * 32 ? ((int)HW >= 64 ? (int)HW & ~7 : (int)HW) : 256 * 32;   // a multiple of 8 (one azimuth sector per XCD) unless tiny
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
             } else { tp.ovf_list = nullptr; }
         }
