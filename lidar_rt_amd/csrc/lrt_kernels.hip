@@ -156,7 +156,7 @@ struct TraceParams {
     // bucketed backward (lrt_bucket.inc): Gaussians in buckets of 2^bk_shift consecutive indices, rays in bk_ng groups of bk_rpg
     uint4* brec; unsigned rec_cap;         // per-hit records (ray << bk_shift | g % 2^bk_shift, t, dL/dalpha, +-w), grouped by bucket
     unsigned* bk_M;                        // [bk_ng][bk_nb] hits of a ray group per bucket -> exclusive prefix over the groups
-    unsigned* bk_tot;                      // [bk_nb] hits per bucket
+    unsigned* bk_aux;                      // [BK_RB][bk_nb] hits per bucket and row block of groups
     unsigned* bk_base;                     // [bk_nb + 1] first record of a bucket
     uint4* brec2; unsigned* bkg;          // the records in Gaussian order (ray, t, dL/dalpha, +-w) and their Gaussian
     int bk_shift, bk_nb, bk_ng, bk_rpg;
@@ -1290,7 +1290,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 const int hw = H * W;
                 const int rpg = hw <= 16 * BK_MAX_NG ? 16 : (hw + BK_MAX_NG - 1) / BK_MAX_NG;
                 const int ng = (hw + rpg - 1) / rpg;
-                const size_t m_words = (size_t)ng * bk_nb, small_words = (size_t)bk_nb * 2 + 2;
+                const size_t m_words = (size_t)ng * bk_nb, small_words = (size_t)bk_nb * (1 + BK_RB) + 2;
                 if (st->key_cap > st->brec_cap || m_words > st->bk_M_words || small_words > st->bk_small_words) {
                     HIPCHK(hipStreamSynchronize(stream));
                     (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
@@ -1304,7 +1304,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 }
                 tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk; tp.hit_wa = st->hit_wa;
                 tp.brec = st->brec; tp.brec2 = st->brec2; tp.bkg = st->bk_g; tp.rec_cap = st->key_cap; tp.bk_M = st->bk_M;
-                tp.bk_tot = st->bk_small; tp.bk_base = st->bk_small + bk_nb;
+                tp.bk_aux = st->bk_small; tp.bk_base = st->bk_small + (size_t)BK_RB * bk_nb;
                 tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg;
                 if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
                 const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
@@ -1315,7 +1315,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                 }
                 hipLaunchKernelGGL(k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
-                hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64)), dim3(1024), 0, stream, tp);
+                hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
                 hipLaunchKernelGGL(k_bk_base, dim3(1), dim3(1024), 0, stream, tp);
                 if (tp.fast_prep) hipLaunchKernelGGL((k_bwd_prep<true, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
                 else hipLaunchKernelGGL((k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
