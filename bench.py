@@ -298,10 +298,10 @@ def main():
         bf, bb = algorithmic_bytes(C, K, deg)
         ms_f = kt["fwd"][0] / max(kt["fwd"][1], 1); ms_b = kt["bwd"][0] / max(kt["bwd"][1], 1)
         ms_build = kt["build"][0] / max(kt["build"][1], 1)
-        dom = "backward (k_bwd_prep + radix sort + k_bwd_reduce3)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
+        dom = "backward (k_bk_count .. k_bwd_prep .. k_bk_sort + k_bwd_reduce4)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
         dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None; valu = None; step_traffic = None; traffic_note = None
+        traffic = None; traffic_raw = None; valu = None; step_traffic = None; step_traffic_raw = None; traffic_note = None
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
@@ -309,8 +309,9 @@ def main():
                 pj = json.load(open(tp))
                 if pj.get("_meta", {}).get("csrc_sha") == source_hash():
                     ent = pj.get(dom, {})
-                    traffic = ent.get("hbm_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
+                    traffic = ent.get("hbm_bytes_per_launch"); traffic_raw = ent.get("raw_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
                     step_traffic = pj.get("whole step (all kernels, per step)", {}).get("hbm_bytes_per_launch")
+                    step_traffic_raw = pj.get("whole step (all kernels, per step)", {}).get("raw_bytes_per_launch")
                     traffic_note = f"rocprofv3 PMC passes of profile '{pj['_meta'].get('tag')}' (profiles/pmc_traffic.json), same kernel sources (hash {source_hash()})"
                 else:
                     traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (hash mismatch): not reported"
@@ -318,6 +319,8 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json unreadable: {ex}"
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
+                # `traffic` applies the guide's gfx950 correction (2 x FETCH_SIZE + WRITE_SIZE); the uncorrected sum beside it
+                "traffic_uncorrected": traffic_raw,
                 # supplementary (committed rocprofv3 PMC profile): the trace kernel is bound by VALU issue, not by HBM
                 "valu_issue_frac": valu,
                 "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
@@ -327,7 +330,9 @@ def main():
                 # sorted-reduction design does not move), and beside it the counter-measured bytes of ALL kernels of a step
                 "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S,
                 "whole_step_frac_counters": (step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S) if (step_traffic and world == 1) else None,
-                "whole_step_traffic": step_traffic if world == 1 else None}
+                "whole_step_traffic": step_traffic if world == 1 else None,
+                "whole_step_frac_counters_uncorrected": (step_traffic_raw / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S) if (step_traffic_raw and world == 1) else None,
+                "whole_step_traffic_uncorrected": step_traffic_raw if world == 1 else None}
         res = {
             "metric": "LiDAR rays/s fwd+bwd @1M Gaussians, 2048x64 sweep; % HBM roofline",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": steps_run, "steps_requested": args.steps, "warmup": args.warmup,

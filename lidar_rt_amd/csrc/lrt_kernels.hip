@@ -189,6 +189,12 @@ __device__ __forceinline__ float wave_sum_f(float x)                     // tota
     x += dpp_f<0x143, 0xc>(0.f, x);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+__device__ __forceinline__ float half_sum_f(float x)                     // totals of lanes 0..31 / 32..63 in lanes 31 / 63
+{
+    x += dpp_f<0x111, 0xf>(0.f, x); x += dpp_f<0x112, 0xf>(0.f, x); x += dpp_f<0x114, 0xf>(0.f, x); x += dpp_f<0x118, 0xf>(0.f, x);
+    x += dpp_f<0x142, 0xa>(0.f, x);
+    return x;
+}
 __device__ __forceinline__ float wave_incl_sum(float x)                  // inclusive prefix sum over the 64 lanes
 {
     x += dpp_f<0x111, 0xf>(0.f, x); x += dpp_f<0x112, 0xf>(0.f, x); x += dpp_f<0x114, 0xf>(0.f, x); x += dpp_f<0x118, 0xf>(0.f, x);
@@ -1189,7 +1195,8 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
             hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
             if (dfr) {
-                const int cb = (int)HW < 256 * 32 ? ((int)HW >= 64 ? (int)HW & ~7 : (int)HW) : 256 * 32;   // a multiple of 8 (one azimuth sector per XCD) unless tiny
+                const int np_ = ((int)HW + 1) / 2;                                                          // two rays per wave
+                const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
             } else { tp.ovf_list = nullptr; }
         }

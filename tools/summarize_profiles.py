@@ -89,10 +89,12 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 
 fw = [traffic[k] for k in traffic if k.startswith("k_fwd_")]
 if fw:
     traffic["forward (k_fwd_cr4 + k_fwd_colour)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in fw),
+                                                      "raw_bytes_per_launch": sum(x["raw_bytes_per_launch"] for x in fw),
                                                       "valu_issue_frac_dominant_kernel": max((x.get("valu_issue_frac", 0.0) for x in fw), default=None)}
-bw = [traffic[k] for k in traffic if k.startswith("k_bwd_")]
+bw = [traffic[k] for k in traffic if k.startswith("k_bwd_") or k.startswith("k_bk_")]
 if bw:
-    traffic["backward (k_bwd_prep + radix sort + k_bwd_reduce3)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw)}
+    traffic["backward (k_bk_count .. k_bwd_prep .. k_bk_sort + k_bwd_reduce4)"] = {"hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] for x in bw),
+                                                                                   "raw_bytes_per_launch": sum(x["raw_bytes_per_launch"] for x in bw)}
 # whole step from the counters: all dispatches of the PMC runs, per step (= per k_fwd_cr4 dispatch)
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}; steps_pmc = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
 for k, c in pmc.items():
