@@ -189,7 +189,18 @@ __device__ __forceinline__ float wave_sum_f(float x)                     // tota
     x += dpp_f<0x143, 0xc>(0.f, x);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
-__device__ __forceinline__ float half_sum_f(float x)                     // totals of lanes 0..31 / 32..63 in lanes 31 / 63
+__device__ __forceinline__ float half_incl_prod(float x)                 // inclusive prefix product inside lanes 0..31 and inside 32..63
+{
+    x *= dpp_f<0x111, 0xf>(1.f, x); x *= dpp_f<0x112, 0xf>(1.f, x); x *= dpp_f<0x114, 0xf>(1.f, x); x *= dpp_f<0x118, 0xf>(1.f, x);
+    x *= dpp_f<0x142, 0xa>(1.f, x);
+    return x;
+}
+__device__ __forceinline__ float half_last(float x, int half)            // the value of lane 31 / 63 of the caller's half
+{
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    return half ? b : a;
+}
+__device__ __forceinline__ float half_sum_f(float x)                     // inclusive prefix sum inside lanes 0..31 and inside 32..63 (totals in lanes 31 / 63)
 {
     x += dpp_f<0x111, 0xf>(0.f, x); x += dpp_f<0x112, 0xf>(0.f, x); x += dpp_f<0x114, 0xf>(0.f, x); x += dpp_f<0x118, 0xf>(0.f, x);
     x += dpp_f<0x142, 0xa>(0.f, x);
@@ -1318,13 +1329,13 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 tp.fast_prep = st->fast_valid;
                 if (lds_nb > 48 * 1024) {
                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
-                    if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+                    if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                     else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                 }
                 hipLaunchKernelGGL(k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
                 hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
                 hipLaunchKernelGGL(k_bk_base, dim3(1), dim3(1024), 0, stream, tp);
-                if (tp.fast_prep) hipLaunchKernelGGL((k_bwd_prep<true, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
+                if (tp.fast_prep) hipLaunchKernelGGL(k_bwd_prep2, dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
                 else hipLaunchKernelGGL((k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
                 hipLaunchKernelGGL(k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
                 hipLaunchKernelGGL(k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
