@@ -174,7 +174,7 @@ def main():
     bg = torch.as_tensor(bg_np, device=dev)
     dL = torch.as_tensor(dL_np, device=dev)
 
-    from lidar_rt_amd.parallel import ShardedTracer
+    from lidar_rt_amd.parallel import ShardedTracer, column_slab
     tr = ShardedTracer(exchange=args.exchange)
     st = tr.backend.state
     for kv in args.opt:
@@ -285,7 +285,7 @@ def main():
         ms_per_step = 1e3 * elapsed / steps_run
         value = n_rays * steps_run / elapsed
         # ---- roofline of the dominant kernel (per launch, this rank's slab)
-        a, b = tr._slab
+        a, b = getattr(tr, "_slab", None) or column_slab(W, rank, world)      # --via tracer never runs ShardedTracer.forward
         rays_local = H * (b - a)
         stats_path = os.path.join(REPO, "tests", "golden", "s1m_stats.json")
         if args.workload == "s1m" and os.path.exists(stats_path):

@@ -136,7 +136,11 @@ int lrt_get_timing(lrt_state* st, double ms_sum[4], int count[4], void* stream);
 /* Debug/test hook: copy an internal buffer of the current build to the host (see lrt_kernels.hip). */
 long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max_bytes, void* stream);
 
-/* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays). */
+/* Tunables (0 = keep default). tile_w: rays per tile row (power of two <= 64; tile = 64 rays).
+ * The ones a caller may want: fwd_mode (2 collect & resolve [default], 0 K-buffer packets); bwd_mode (3 bucketed replay [default],
+ * 2 sorted replay, 1 replay + atomics, 0 re-trace like backward.cu:513); defer_colour; hit_cap (composited hits recorded per ray, 256);
+ * spec_bwd; defer_errors; refine_ties (1: hits closer than 2 ulp are ordered by their fp64 distance); lag_bounds (1: Morton box of
+ * the previous build); root_nodes (32); slab0_mm (first depth slab, 100000); the full list is lrt_set_option in lrt_kernels.hip. */
 int lrt_set_option(lrt_state* st, const char* name, int value);
 /* Current value of an option (hit_cap, hit_cap_auto, fwd_mode, bwd_mode, reduce_mode, defer_colour, c4_waves): hit_cap can grow
  * by itself, see lrt_kernels.hip. */
