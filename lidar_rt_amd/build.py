@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblrt_hip.so")
 SOURCES = ["lrt_kernels.hip", "lrt_chamfer.hip", "lrt_preprocess.hip"]
-HEADERS = ["lrt_math.h", "lrt_device_guard.h", "lrt_build.inc", "lrt_backward.inc", "lrt_trace_legacy.inc", "lrt_collect.inc", "lrt_collect4.inc", "lrt_radix.inc", "lrt_near.inc", os.path.join("..", "..", "include", "lrt.h"),
+HEADERS = ["lrt_math.h", "lrt_device_guard.h", "lrt_build.inc", "lrt_backward.inc", "lrt_trace_legacy.inc", "lrt_collect.inc", "lrt_collect4.inc", "lrt_radix.inc", "lrt_near.inc", "lrt_bucket.inc", os.path.join("..", "..", "include", "lrt.h"),
            os.path.join("..", "..", "include", "lrt_chamfer.h"), os.path.join("..", "..", "include", "lrt_knn.h"),
            os.path.join("..", "..", "include", "lrt_preprocess.h")]
 ARCH = "gfx950"

@@ -222,6 +222,31 @@ def test_own_radix_sort_and_rocprim_give_the_same_results():
                 assert rel_l2(got["grads"][k], ref["grads"][k]) < 5e-7, (P, k)   # up to the float atomics of runs that span two waves (1.3e-7 seen)
 
 
+def test_bucketed_backward_against_the_sorted_one_on_awkward_index_layouts():
+    """bwd_mode 3 (count / scatter / LDS sort per bucket / flat reduction) against bwd_mode 2 (key sort + segmented reduction) where the
+    bucket machinery is stressed: Gaussian indices ordered by distance from the sensor (the near, heavily hit Gaussians share a few
+    buckets: tens of thousands of records in one bucket, empty buckets elsewhere), P not a multiple of the bucket size, P smaller than
+    one bucket, a single ray column, an image smaller than one ray group."""
+    cases = []
+    sc = scenes.make_scene(30_011, seed=11, radius_scale=0.25)
+    order = np.argsort(np.linalg.norm(sc["means"], axis=1), kind="stable")
+    cases.append(({k: np.ascontiguousarray(v[order]) for k, v in sc.items()}, (16, 256)))
+    cases.append((scenes.make_scene(19, seed=12, radius_scale=0.1), (8, 64)))
+    cases.append((scenes.make_scene(5_000, seed=13, radius_scale=0.2), (64, 1)))
+    cases.append((scenes.make_scene(700, seed=14, radius_scale=0.1), (2, 3)))
+    for sc, (H, W) in cases:
+        o, d = scenes.kitti_rays(H, W)
+        dL = scenes.upstream_grad(H, W)
+        ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"bwd_mode": 2})
+        for rep in range(2):                                                   # twice: the buffers of the first call are reused
+            got = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"bwd_mode": 3})
+            np.testing.assert_array_equal(got["out"], ref["out"])
+            for k in GRADS:
+                assert np.isfinite(got["grads"][k]).all()
+                assert rel_l2(got["grads"][k], ref["grads"][k]) < 5e-6, (len(sc["means"]), H, W, k)     # other summation order inside a Gaussian's run
+                assert ((got["grads"][k] != 0) == (ref["grads"][k] != 0)).mean() > 0.9999              # rows of untouched Gaussians are zeros, not leftovers
+
+
 # ---------------------------------------------------------------------------------- larger scenes, statistical parity
 def test_s200k_matches_oracle_within_noise_floor():
     sc = scenes.make_scene(200_000, radius_scale=0.5)
