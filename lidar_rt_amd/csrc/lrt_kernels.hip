@@ -150,6 +150,7 @@ struct TraceParams {
     float* tile_w0;        // k_fwd_cr4: per tile, the first-slab width learnt in the previous frame (0 = none yet)
     // rays with a quad closer than LRT_T_NEAR: listed by the trace kernel, resolved by k_fwd_near (the reference's stale-slot rule)
     int* near_list; unsigned* near_count;
+    unsigned* near_done; const float* naos;   // re-tracing backward: finished-workgroup counter (its last workgroup replays the near rays), AoS nodes for that replay
     unsigned root_first, root_count;   // k_fwd_cr4: the nodes its walk starts from (a whole level of the tree)
     unsigned c4_qlimit;    // k_fwd_cr4: queue occupancy that triggers the halve-the-slab fallback (<= C4_NQ; lower values only for tests)
     const float4* pack;    // k_fwd_cr4: the build's packed raw parameters (fp64 re-evaluation of depths closer than 2 ulp), or null
@@ -401,11 +402,11 @@ __global__ void __launch_bounds__(256) k_list_foreign(int P, int rank, int cap, 
 
 __global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (float)(ctrl[10] | ctrl[12]); }
 
+#include "lrt_near.inc"
 #include "lrt_trace_legacy.inc"
 
 #include "lrt_collect.inc"
 #include "lrt_collect4.inc"
-#include "lrt_near.inc"
 
 __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 {
@@ -419,7 +420,8 @@ __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ acc
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
-    // [12] STICKY error bits (only the host clears them), [16..23] tile queues of a re-tracing backward
+    // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
+    // [24] near rays found by the re-tracing backward, [25] its finished workgroups
     if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
@@ -1043,7 +1045,7 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
     if (bwd && st->bwdq_fresh) { tp.tile_counter = st->ctrl + 16; st->bwdq_fresh = 0; }       // zeroed by the forward's prologue, used once
-    else HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream));
+    else { HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream)); if (bwd) HIPCHK(hipMemsetAsync(st->ctrl + 24, 0, 2 * sizeof(unsigned), stream)); }
     int blocks = (tp.n_tiles + 3) / 4;
     if (blocks > 256 * 3) blocks = 256 * 3;                       // persistent: <= 3 blocks (12 waves) per CU
     ScopedTimer tm(st, tp.guard == 2 ? -1 : (bwd ? 2 : 1), stream);      // the guarded fallback lies inside the caller's timed region
@@ -1095,7 +1097,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     if (HW > st->near_cap) {
         HIPCHK(hipStreamSynchronize(stream));
         (void)hipFree(st->near_list); st->near_list = nullptr; st->near_cap = 0;
-        HIPCHK(hipMalloc(&st->near_list, HW * sizeof(int)));
+        HIPCHK(hipMalloc(&st->near_list, 2 * HW * sizeof(int)));      // [0, HW): the forward's list, [HW, 2 HW): the re-tracing backward's own
         st->near_cap = HW;
     }
     tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
@@ -1266,6 +1268,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.means = means; tp.scales = scales; tp.rots = rots; tp.opac = opac; tp.mod = st->mod;
     tp.out9_in = out9; tp.dL_dout = dL_dout9;
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
+    // the re-tracing backward finds the rays with a quad closer than 0.2 m itself and replays them like k_fwd_near does (lrt_near.inc)
+    if (st->near_list && (size_t)H * W <= st->near_cap) { tp.near_list = st->near_list + st->near_cap; tp.near_count = st->ctrl + 24; tp.near_done = st->ctrl + 25; tp.naos = (const float*)st->nodes_aos; }
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
         // The sort and the reduction are sized by the number of composited hits, which the forward counted on the device.  If its
         // status block has already reached the host the exact number is used.  Otherwise the host does NOT wait (the launch queue

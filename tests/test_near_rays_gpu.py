@@ -14,11 +14,12 @@ if torch.cuda.is_available():
     from tests.hip_util import run_hip, rel_l2, frac_outside
     from tests.test_hip_parity import _facing, oracle_run
 
-MODES = [{"fwd_mode": 2, "defer_colour": 1}, {"fwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "defer_colour": 1, "c4_waves": 8}]
-IDS = ["collect4-defer", "collect4", "legacy-forward", "collect4-8waves"]
+MODES = [{"fwd_mode": 2, "defer_colour": 1}, {"fwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "defer_colour": 1, "c4_waves": 8},
+         {"fwd_mode": 2, "defer_colour": 1, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 0}]      # the last two: the re-tracing backward replays the near rays itself
+IDS = ["collect4-defer", "collect4", "legacy-forward", "collect4-8waves", "collect4-retrace-bwd", "legacy-retrace-bwd"]
 
 
-@pytest.mark.parametrize("mode", MODES, ids=IDS)
+@pytest.mark.parametrize("mode", MODES[:4], ids=IDS[:4])
 def test_known_answers_with_a_hit_below_the_near_threshold(mode):
     # the ray passes a little off the quads' centres: through a centre it would hit the shared edge of a quad's two triangles, and
     # the reference would then spend two K-buffer slots on one quad
@@ -56,7 +57,7 @@ def test_known_answers_with_a_hit_below_the_near_threshold(mode):
     np.testing.assert_allclose(h["accum"], fw["accum"], rtol=2e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("mode", MODES[:3], ids=IDS[:3])
+@pytest.mark.parametrize("mode", MODES[:3] + MODES[4:], ids=IDS[:3] + IDS[4:])
 def test_sensor_inside_the_geometry_matches_the_oracle(mode):
     """A sensor in the middle of dense clutter: about a third of the rays have a quad within 0.2 m.  Forward and (replay) backward
     against the oracle whose any-hit program is fed in ascending t, the realisation of the reference's order-dependent
@@ -83,6 +84,6 @@ def test_sensor_inside_the_geometry_matches_the_oracle(mode):
     assert (err[near] > 1e-3).mean() <= 0.03 and (err[~near] > 1e-3).mean() <= 0.01, ((err[near] > 1e-3).mean(), (err[~near] > 1e-3).mean())
     assert rel_l2(h["out"], fw["out"]) < 5e-3
     assert rel_l2(h["accum"], fw["accum"]) < 1e-2
-    if mode.get("fwd_mode") == 2:                # replay backward of the recorded (near-ray) hits
+    if mode.get("fwd_mode") == 2 or mode.get("bwd_mode") == 0:     # replay backward of the recorded (near-ray) hits / re-tracing backward with its own near-ray replay
         for k in ("means", "opacities", "shs"):
-            assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 5e-2, k
+            assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 2e-3, k        # measured < 5e-5 in every mode (tests/tools/near_dbg.py)
