@@ -90,15 +90,17 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 int32_t* out_i32, float* accum, void* stream);
 
 /* Backward trace (TraceSurfelsBackwardCUDA).  After a forward with training != 0 on the same state it replays that forward's
- * composited-hit record (per-ray preparation -> radix sort by Gaussian -> segmented reduction); otherwise it re-traces like the
- * reference (backward.cu:513) and scatters with atomics.
+ * composited-hit record (hits counted per bucket of Gaussians -> per-ray preparation scatters one 16-byte record per hit into its
+ * bucket -> per-bucket sort in LDS -> segmented reduction; option "bwd_mode" = 2: radix sort of (Gaussian, hit) keys instead);
+ * otherwise it re-traces like the reference (backward.cu:513) and scatters with atomics.
  *   means/scales/rotations/opacities: the same parameter tensors given to lrt_build.
  *   out9: forward output; dL_dout9 (H,W,9): upstream gradient.
- *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): zero-filled, then accumulated.
+ *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): OUTPUTS, every element is written (no need to
+ *   clear them; the paths that accumulate zero-fill first).
  * Stream order: the call does not wait for the forward.  If the forward's status (its composited-hit count) has not reached the
- * host yet, the sort is sized from the last completed forward of the same image size (x 1.125 + 64 k) and the kernels decide on
- * the device between the sorted reduction and the re-tracing fallback (both enqueued; the one not needed returns at once).  Only
- * the first backward of an image size waits for its forward (option "spec_bwd" = 0: every backward does). */
+ * host yet, the work is enqueued anyway (bwd_mode 2: the sort sized from the last completed forward of the same image size, x 1.125 +
+ * 64 k) and the kernels decide on the device between the replay and the re-tracing fallback (both enqueued; the one not needed
+ * returns at once).  Only the first backward of an image size waits for its forward (option "spec_bwd" = 0: every backward does). */
 int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M,
                  int sh_degree, const float* means, const float* scales, const float* rotations,
                  const float* opacities, const float* shs, const float* background, const float* out9,
