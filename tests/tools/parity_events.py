@@ -14,7 +14,7 @@ Rays with IDENTICAL sequences differ by arithmetic only; those beyond tolerance 
 composited alpha lies within 1e-5 of the clamp).  Output: a table per implementation (rays per class, rays of the class whose
 intensity / ray-drop / depth leave 1e-4) -> profiles/<tag>_parity_events.{json,md}.
 
-    python tools/parity_events.py [s1m|s200k|s10k] [tag]
+    python tests/tools/parity_events.py [s1m|s200k|s10k] [tag]
 """
 import ctypes as C
 import json
@@ -24,10 +24,10 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes                      # noqa: E402
 from lidar_rt_amd.parallel import HipBackend        # noqa: E402
-from oracle import oracle                           # noqa: E402  (developer tool: the checker is allowed here, not in the product)
+from oracle import oracle                           # noqa: E402  (a checker under tests/: the only place besides smoke() and bench.py that may use the oracle)
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "s1m"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
