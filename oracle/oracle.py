@@ -102,7 +102,7 @@ class Oracle:
         return res
 
     def forward_trace(self, ray_o, ray_d, shs, sh_degree: int, bg, cap: int = 160) -> Dict[str, np.ndarray]:
-        """The forward with a per-ray EVENT TRACE (tools/parity_events.py): every candidate in the order the raygen loop looks at it:
+        """The forward with a per-ray EVENT TRACE (tests/tools/parity_events.py): every candidate in the order the raygen loop looks at it:
         n (H,W), g / t / alpha (un-clamped) / flags (H,W,cap); flags: 1 composited, 2 skipped (alpha < 1/255), 4 stopped the ray,
         8 first candidate after a restart."""
         t = self.np_t
