@@ -132,7 +132,9 @@ def main():
                     "with preallocated gradient views; tracer: the DROP-IN path a maintainer gets -- diff_lidar_tracer.Tracer -> torch.autograd -> `_C` "
                     "(fresh output / gradient tensors per call, the three dead zero outputs), N = 1 only.  The line always carries the other path's "
                     "rays/s as `drop_in_path` / `direct_path` when --both-paths is given")
-    ap.add_argument("--both-paths", action="store_true", help="time the other --via path too (same window length) and report it beside `value`")
+    ap.add_argument("--both-paths", dest="both_paths", action="store_true", default=True,
+                    help="(default on one GPU) time the other --via path too, same window length, and report it beside `value` as `drop_in_path` / `direct_path`")
+    ap.add_argument("--no-both-paths", dest="both_paths", action="store_false", help="time only the --via path")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
                     "configuration: the reference rebuilds its acceleration structure on every call, and so does the default step)")

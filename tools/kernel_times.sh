@@ -2,7 +2,7 @@
 # usage: tools/kernel_times.sh <tag> [bench args...]   (run on the GPU box; prints per-step kernel times from rocprofv3)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/$tag -- python /root/repo/bench.py --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0 "$@" > /root/repo/gpurun_out/$tag.bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/$tag -- python /root/repo/bench.py --no-cpu-baseline --no-both-paths --steps 10 --warmup 2 --min-seconds 0 "$@" > /root/repo/gpurun_out/$tag.bench.log 2>&1
 cd /root/repo
 python - "$tag" <<'PY'
 import csv, glob, sys

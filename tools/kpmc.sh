@@ -5,7 +5,7 @@ K=$1; C=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/kpmc_tmp
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d $OUT -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --min-seconds 0 "$@" > /dev/null 2> $OUT/err.txt
+timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d $OUT -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-both-paths --min-seconds 0 "$@" > /dev/null 2> $OUT/err.txt
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/**/*counter_collection.csv", recursive=True)

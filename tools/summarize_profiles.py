@@ -48,7 +48,7 @@ except Exception:
     pass
 
 traffic = {}
-lines = [f"# rocprofv3 summary `{tag}` (MI355X, `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --min-seconds 0`)\n",
+lines = [f"# rocprofv3 summary `{tag}` (MI355X, `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-both-paths --min-seconds 0`: the direct path only)\n",
          "Raw rocprofv3 outputs were written under `gpurun_out/prof_%s/` on the GPU box; this file is the committed digest.\n" % tag]
 if bench:
     lines.append(f"bench line under `--kernel-trace --stats`: **{bench['value']/1e6:.2f} M rays/s**, {bench['ms_per_step']:.3f} ms/step; "
