@@ -136,6 +136,8 @@ def main():
                     help="(default on one GPU) time the other --via path too, same window length, and report it beside `value` as `drop_in_path` / `direct_path`")
     ap.add_argument("--no-both-paths", dest="both_paths", action="store_false", help="time only the --via path")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
+    ap.add_argument("--no-stats-step", action="store_true", help="skip the one instrumented (untimed) step that collects the traversal counters: the profiling "
+                    "scripts use it so that every kernel of the trace is a kernel of a regular step (the counters' k_fwd_cr4<.., true> instantiation is not)")
     ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
                     "configuration: the reference rebuilds its acceleration structure on every call, and so does the default step)")
     args = ap.parse_args()
@@ -264,10 +266,11 @@ def main():
         barrier(); other = H * W * steps_run / (time.perf_counter() - t1)
 
     # ---------------- one instrumented step for the traversal statistics (untimed)
-    st.enable_stats(True)
+    if not args.no_stats_step:
+        st.enable_stats(True)
     out, g = step()
     torch.cuda.synchronize()
-    hs = st.get_stats(dev)
+    hs = st.get_stats(dev) if not args.no_stats_step else {}
     st.enable_stats(False)
 
     cks = None
@@ -295,7 +298,7 @@ def main():
             C, K = gs["C_mean_candidates_per_ray"], gs["K_mean_composited_per_ray"]
             ck_src = "oracle (tests/golden/s1m_stats.json)"
         else:
-            C = hs["candidates"] / 2.0 / max(rays_local, 1); K = hs["composited"] / 2.0 / max(rays_local, 1)
+            C = hs.get("candidates", 0) / 2.0 / max(rays_local, 1); K = hs.get("composited", 0) / 2.0 / max(rays_local, 1)
             ck_src = "HIP counters of this run"
         bf, bb = algorithmic_bytes(C, K, deg)
         ms_f = kt["fwd"][0] / max(kt["fwd"][1], 1); ms_b = kt["bwd"][0] / max(kt["bwd"][1], 1)
@@ -303,33 +306,64 @@ def main():
         dom = "backward (k_bk_count .. k_bwd_prep .. k_bk_sort + k_bwd_reduce4)" if ms_b >= ms_f else "forward (k_fwd_cr4 + k_fwd_colour)"
         dom_ms = max(ms_b, ms_f); dom_bytes = (bb if ms_b >= ms_f else bf) * rays_local
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        ms_c = kt["colour"][0] / max(kt["colour"][1], 1) if "colour" in kt else 0.0
+        n_sh = 12 * (deg + 1) ** 2
+        # algorithmic bytes per ray of the SURVEY 8(d) model, split by kernel: the trace kernel reads the rays, the candidates' splat
+        # parameters and adds the hit weights (8 B read-modify-write per composited hit); the colour pass reads the SH rows; the build
+        # is not part of the SURVEY model (its node bytes are "implementation specific"): inputs + records + nodes of the LBVH, per step
+        P_ = int(sc["means"].shape[0])
+        alg = {"k_fwd_cr4": (24 + 36 + 40 * C + 8 * K) * rays_local, "k_fwd_colour": n_sh * K * rays_local,
+               "backward": bb * rays_local, "build": float(P_) * (40 + 64) + (P_ / 8.0 / 7.0) * 256 * 2}
+        live_ms = {"k_fwd_cr4": max(ms_f - ms_c, 0.0), "k_fwd_colour": ms_c, "backward": ms_b, "build": ms_build}
         traffic = None; traffic_raw = None; valu = None; step_traffic = None; step_traffic_raw = None; traffic_note = None
+        per_kernel = {k: {"algorithmic_bytes": alg[k], "live_ms": live_ms[k],
+                          "frac_algorithmic": (alg[k] / (live_ms[k] * 1e-3) / HBM_PEAK_BYTES_PER_S) if live_ms[k] > 0 else None} for k in alg}
+        per_kernel["k_fwd_cr4"]["live_ms_note"] = "forward region minus the colour pass (includes k_fwd_near, a few us)"
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 from lidar_rt_amd.build import source_hash
                 pj = json.load(open(tp))
-                if pj.get("_meta", {}).get("csrc_sha") == source_hash():
-                    ent = pj.get(dom, {})
-                    traffic = ent.get("hbm_bytes_per_launch"); traffic_raw = ent.get("raw_bytes_per_launch"); valu = ent.get("valu_issue_frac_dominant_kernel")
-                    step_traffic = pj.get("whole step (all kernels, per step)", {}).get("hbm_bytes_per_launch")
-                    step_traffic_raw = pj.get("whole step (all kernels, per step)", {}).get("raw_bytes_per_launch")
-                    traffic_note = f"rocprofv3 PMC passes of profile '{pj['_meta'].get('tag')}' (profiles/pmc_traffic.json), same kernel sources (hash {source_hash()})"
-                else:
+                if pj.get("_meta", {}).get("csrc_sha") == source_hash() and "regions" in pj and args.workload == "s1m" and world == 1:
+                    regs, kern = pj["regions"], pj["kernels"]
+                    region_key = "backward" if ms_b >= ms_f else "forward"
+                    traffic = regs[region_key]["corrected_bytes_per_step"]; traffic_raw = regs[region_key]["raw_bytes_per_step"]
+                    step_traffic = pj["step"]["corrected_bytes_per_step"]; step_traffic_raw = pj["step"]["raw_bytes_per_step"]
+                    cr4 = [k for k in kern if k.startswith("k_fwd_cr4") and kern[k]["region"] == "forward"]
+                    valu = max((kern[k].get("valu_issue_frac", 0.0) for k in cr4), default=None)
+                    src_rows = {"k_fwd_cr4": cr4, "k_fwd_colour": ["k_fwd_colour"], "backward": regs["backward"]["kernels"], "build": regs["build"]["kernels"]}
+                    for name, ks in src_rows.items():
+                        ks = [k for k in ks if k in kern and kern[k]["launches_per_step"]]
+                        corr = sum(kern[k]["corrected_bytes_per_launch"] * kern[k]["launches_per_step"] for k in ks)
+                        raw = sum(kern[k]["raw_bytes_per_launch"] * kern[k]["launches_per_step"] for k in ks)
+                        us = sum((kern[k]["avg_us"] or 0.0) * kern[k]["launches_per_step"] for k in ks)
+                        per_kernel[name].update({"counter_bytes": corr, "counter_bytes_uncorrected": raw, "profile_us": us,
+                                                 "frac_counters": corr / (us * 1e-6) / HBM_PEAK_BYTES_PER_S if us > 0 else None,
+                                                 "frac_counters_uncorrected": raw / (us * 1e-6) / HBM_PEAK_BYTES_PER_S if us > 0 else None,
+                                                 "profile_kernels": ks})
+                    traffic_note = (f"rocprofv3 PMC passes of profile '{pj['_meta'].get('tag')}' (profiles/pmc_traffic.json, profiles/{pj['_meta'].get('tag')}_summary.md), "
+                                    f"same kernel sources (hash {source_hash()}); per step = per-launch average x launches per step")
+                elif pj.get("_meta", {}).get("csrc_sha") != source_hash():
                     traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (hash mismatch): not reported"
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was collected on S1M with one GPU: not reported for this configuration"
             except Exception as ex:
                 traffic_note = f"profiles/pmc_traffic.json unreadable: {ex}"
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
-                # `traffic` applies the guide's gfx950 correction (2 x FETCH_SIZE + WRITE_SIZE); the uncorrected sum beside it
+                # `traffic` = counter bytes per step of the dominant region's kernels with the guide's gfx950 correction (2 x FETCH_SIZE +
+                # WRITE_SIZE); the uncorrected sum beside it; which applies to which access pattern: profiles/r04_fetch_calibration.md
                 "traffic_uncorrected": traffic_raw,
                 # supplementary (committed rocprofv3 PMC profile): the trace kernel is bound by VALU issue, not by HBM
                 "valu_issue_frac": valu,
                 "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
-                "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b},
+                "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b, "colour_pass": ms_c},
+                # per kernel / region: algorithmic bytes (SURVEY 8(d) split), live HIP-event time of this run, and -- from the committed
+                # profile of the same sources -- counter bytes (corrected / raw), rocprofv3 kernel time and the fractions of 8 TB/s
+                "per_kernel": per_kernel,
                 "traffic_source": traffic_note,
                 # whole step: the SURVEY 8(d) byte model (its backward term, 58 read-modify-write atomics per hit, is traffic the
-                # sorted-reduction design does not move), and beside it the counter-measured bytes of ALL kernels of a step
+                # replay design does not move), and beside it the counter-measured bytes of ALL kernels of a step
                 "whole_step_frac": (bf + bb) * n_rays / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S,
                 "whole_step_frac_counters": (step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S) if (step_traffic and world == 1) else None,
                 "whole_step_traffic": step_traffic if world == 1 else None,

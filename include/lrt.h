@@ -44,7 +44,8 @@ typedef struct lrt_state lrt_state;
 #define LRT_ERR_HIP (-2)
 #define LRT_ERR_STATE (-3)
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change); lrt_abi_version() is what the loaded library was built from. */
+#define LRT_ABI_VERSION 3
 int lrt_abi_version(void);
 
 /* Text of the last error on the calling thread ("" if none). */
@@ -130,8 +131,9 @@ int lrt_check_forward(lrt_state* st, int wait);
 int lrt_enable_stats(lrt_state* st, int enable);
 int lrt_get_stats(lrt_state* st, uint64_t stats_out[8], void* stream);
 
-/* HIP-event timing on the caller's stream: index 0 = whole lrt_build region, 1 = forward trace kernel,
- * 2 = backward trace kernel.  lrt_get_timing synchronises `stream`, returns summed ms + launch counts, resets. */
+/* HIP-event timing on the caller's stream: index 0 = whole lrt_build region, 1 = forward region (k_fwd_cr4 + k_fwd_near +
+ * k_fwd_colour), 2 = backward region, 3 = k_fwd_colour alone (inside region 1).  lrt_get_timing synchronises `stream`, returns
+ * summed ms + launch counts, resets. */
 int lrt_enable_timing(lrt_state* st, int enable);
 int lrt_get_timing(lrt_state* st, double ms_sum[4], int count[4], void* stream);
 

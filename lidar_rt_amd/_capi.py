@@ -24,6 +24,8 @@ EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lr
            # include/lrt_preprocess.h
            "lrt_preprocess_forward", "lrt_preprocess_backward")
 
+ABI_VERSION = 3          # LRT_ABI_VERSION of include/lrt.h this binding was written against
+
 _lib = None
 
 
@@ -85,7 +87,7 @@ def load():
     lib.lrt_knn_mean_dist2.restype = ci; lib.lrt_knn_mean_dist2.argtypes = [vp, ci, vp, vp, vp]
     lib.lrt_preprocess_forward.restype = ci; lib.lrt_preprocess_forward.argtypes = [ci, ci, ci] + [vp] * 11
     lib.lrt_preprocess_backward.restype = ci; lib.lrt_preprocess_backward.argtypes = [ci, ci, ci] + [vp] * 14
-    if lib.lrt_abi_version() != 2:
+    if lib.lrt_abi_version() != ABI_VERSION:
         raise LrtError("liblrt_hip.so ABI version mismatch; rebuild with `python -m lidar_rt_amd.build --force`")
     if os.environ.get("LRT_TRACE_CALLS"):                    # developer aid: name every entry point on stderr and wait for the device after it
         lib = _TraceCalls(lib)

@@ -507,7 +507,7 @@ struct ScopedTimer {
 
 extern "C" {
 
-int lrt_abi_version(void) { return 2; }
+int lrt_abi_version(void) { return LRT_ABI_VERSION; }
 const char* lrt_last_error(void) { return g_err; }
 // the same buffer for the other translation units of this library (lrt_chamfer.hip); not part of the ABI
 __attribute__((visibility("hidden"))) char* lrt_internal_errbuf(void) { return g_err; }
@@ -821,7 +821,7 @@ int lrt_enable_timing(lrt_state* st, int enable)
     return LRT_OK;
 }
 
-/* ms_sum[k], count[k] for k = 0 build region, 1 forward trace kernel, 2 backward trace kernel; resets the log. */
+/* ms_sum[k], count[k] for k = 0 build region, 1 forward region (trace + near + colour kernels), 2 backward region, 3 the colour pass alone; resets the log. */
 int lrt_get_timing(lrt_state* st, double ms_sum[4], int count[4], void* stream_)
 {
     if (!st || !ms_sum || !count) LRT_FAIL(LRT_ERR_ARG, "lrt_get_timing: null argument");
@@ -1212,6 +1212,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             if (dfr) {
                 const int np_ = ((int)HW + 1) / 2;                                                          // two rays per wave
                 const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
+                ScopedTimer tmc(st, 3, stream);                                                             // the colour pass by itself (inside the forward region's timer)
                 hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
             } else { tp.ovf_list = nullptr; }
         }
@@ -1307,7 +1308,9 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 if ((((long long)P + (1 << bk_shift) - 1) >> bk_shift) > BK_MAX_NB) bk_shift = 9;
                 bk_nb = ((long long)P + (1 << bk_shift) - 1) >> bk_shift;
             }
-            const bool bucket = bk_nb > 0 && bk_nb <= BK_MAX_NB && ((unsigned long long)H * W) < (1ull << (32 - bk_shift)) && tp.n_tiles > 0 && (spec || n_hits > 0);
+            // a gradient row goes out with one lane per component (bk_row_out): 10 + 3 M <= 64, i.e. M <= 18; wider SH tables (M = 25 with an
+            // active degree <= 3) take the sorted path, which zero-fills the tensors first
+            const bool bucket = bk_nb > 0 && bk_nb <= BK_MAX_NB && ((unsigned long long)H * W) < (1ull << (32 - bk_shift)) && tp.n_tiles > 0 && (spec || n_hits > 0) && 10 + 3 * M <= 64;
             if (!bucket) { rc = zero_grads(); if (rc) return rc; }
             if (bucket) {
                 ScopedTimer tm(st, 2, stream);

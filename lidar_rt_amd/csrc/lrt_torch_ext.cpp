@@ -36,6 +36,7 @@ struct State {                                   // the reference's OptiXStateWr
     std::string pkg_dir;
     std::map<int, lrt_state*> handles;
     std::map<int, bool> dirty;
+    std::map<int, bool> refit_next;              // build_acceleration_structure(rebuild = 0): the next build of an unchanged P is an lrt_refit (trace_surfels.cpp:63-73)
     std::map<int, int> built_P, since_full, full_P;
     std::map<int, float> built_mod;
     std::map<std::string, int> options;
@@ -63,7 +64,7 @@ struct State {                                   // the reference's OptiXStateWr
         options[name] = value;
         for (auto& kv : handles) check_rc(lrt_set_option(kv.second, name.c_str(), value), "lrt_set_option");
     }
-    void mark_dirty() { for (auto& kv : dirty) kv.second = true; }
+    void mark_dirty(bool refit = false) { for (auto& kv : dirty) { kv.second = true; refit_next[kv.first] = refit; } }
 };
 
 int device_index(const at::Tensor& t)
@@ -91,12 +92,13 @@ bool present(const c10::optional<at::Tensor>& t) { return t.has_value() && t->de
 
 void build_acceleration_structure(State& st, const at::Tensor& vertices, const at::Tensor& triangles, unsigned rebuild)
 {
-    (void)rebuild;
     // shape checks and messages of DLT/trace_surfels.cpp:53-58
     if (vertices.dim() != 2 || vertices.size(1) != 3) AT_ERROR("vertices must have dimensions (num_vertices, 3)");
     if (triangles.dim() != 2 || triangles.size(1) != 3) AT_ERROR("triangles must have dimensions (num_triangles, 3)");
     TORCH_CHECK(vertices.is_cuda() && triangles.is_cuda(), "vertices/triangles must be CUDA tensors");
-    st.mark_dirty();
+    // rebuild == 0 is the reference's OPTIX_BUILD_OPERATION_UPDATE (trace_surfels.cpp:63-73: same topology, new vertex positions): the
+    // structure is refitted (lrt_refit) when the next trace finds the number of Gaussians of the last full build, rebuilt otherwise
+    st.mark_dirty(rebuild == 0u);
     st.handle(device_index(vertices));            // create the per-device state eagerly (errors surface here)
 }
 
@@ -118,7 +120,11 @@ void build_from_gaussians(State& st, const at::Tensor& means3D, const at::Tensor
     void* stream = (void*)c10::hip::getCurrentHIPStream(idx).stream();
     if (!cull_rays.has_value()) {
         auto since = st.since_full.find(idx);
-        if (st.refit_interval > 0 && since != st.since_full.end() && since->second >= 0 && since->second < st.refit_interval && st.full_P[idx] == (int)P) {
+        const bool can_refit = since != st.since_full.end() && since->second >= 0 && st.full_P[idx] == (int)P && P > 0;
+        auto rn = st.refit_next.find(idx);
+        const bool asked = rn != st.refit_next.end() && rn->second;
+        if (rn != st.refit_next.end()) rn->second = false;
+        if (can_refit && (asked || (st.refit_interval > 0 && since->second < st.refit_interval))) {
             check_rc(lrt_refit(h, (int)P, fptr(m), fptr(s), fptr(r), fptr(o), (float)scale_modifier, stream), "lrt_refit");
             since->second += 1;
         } else {
@@ -241,6 +247,10 @@ trace_surfels_backward(State& st, const at::Tensor& ray_o, const at::Tensor& ray
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod)
 {
     mod.doc() = "MI355X-native diff_lidar_tracer._C (PyTorch-ROCm C++ extension on liblrt_hip.so)";
+    // a stale extension must not bind a newer (or older) library: the header this file was compiled against names the ABI it expects
+    if (lrt_abi_version() != LRT_ABI_VERSION)
+        throw std::runtime_error("diff_lidar_tracer._C_ext was built for liblrt_hip ABI " + std::to_string(LRT_ABI_VERSION) + " but the loaded library reports " +
+                                 std::to_string(lrt_abi_version()) + ": rebuild with `python -m lidar_rt_amd.build --force`");
     // failures of the C ABI raise lidar_rt_amd._capi.LrtError (a RuntimeError), the class the ctypes binding raises
     py::register_exception_translator([](std::exception_ptr p) {
         try { if (p) std::rethrow_exception(p); }
@@ -261,7 +271,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod)
         .def("handle_ptr", [](State& s, int idx) { return (uintptr_t)s.handle(idx); }, "lrt_state* of device `idx` (created on first use)")
         .def("handles", [](State& s) { std::map<int, uintptr_t> m; for (auto& kv : s.handles) m[kv.first] = (uintptr_t)kv.second; return m; })
         .def("set_option", &State::set_option)
-        .def("mark_dirty", &State::mark_dirty);
+        .def("mark_dirty", &State::mark_dirty, py::arg("refit") = false);
     mod.def("build_acceleration_structure", &build_acceleration_structure, py::arg("state"), py::arg("vertices"), py::arg("triangles"), py::arg("rebuild") = 1u);
     mod.def("build_from_gaussians", &build_from_gaussians, py::arg("state"), py::arg("means3D"), py::arg("scales"), py::arg("rotations"), py::arg("opacities"),
             py::arg("scale_modifier") = 1.0, py::arg("cull_rays") = py::none());

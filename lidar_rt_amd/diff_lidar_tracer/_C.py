@@ -97,7 +97,7 @@ class _StateAPI:
             self._lib.lrt_enable_timing(h, 1 if enable else 0)
 
     def get_timing(self, device=None):
-        """HIP-event timings since the last call: {'build'|'fwd'|'bwd': (sum_ms, count)}."""
+        """HIP-event timings since the last call: {'build'|'fwd'|'bwd'|'colour': (sum_ms, count)} ('colour' lies inside 'fwd')."""
         import ctypes as C
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         idx, h = self.handle(device)
@@ -105,7 +105,7 @@ class _StateAPI:
         with torch.cuda.device(idx):
             s = torch.cuda.current_stream().cuda_stream
             _capi.check(self._lib.lrt_get_timing(h, ms, cnt, C.c_void_p(s)), "lrt_get_timing")
-        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(("build", "fwd", "bwd"))}
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(("build", "fwd", "bwd", "colour"))}
 
 
 
@@ -118,6 +118,7 @@ class _CtypesState(_StateAPI):
         self._lib = _capi.load()
         self._handles = {}          # device index -> lrt_state*
         self._dirty = {}            # device index -> bool
+        self._refit_next = {}       # device index -> bool: build_acceleration_structure(rebuild=0) asked for an update (refit)
         self._built_P = {}
         self._built_mod = {}        # device index -> scale modifier of the current structure
         self.refit_interval = 0     # > 0: that many lrt_refit calls between full builds of an unchanged number of Gaussians
@@ -147,9 +148,10 @@ class _CtypesState(_StateAPI):
                 _capi.check(self._lib.lrt_set_option(h, k.encode(), int(v)), "lrt_set_option")
         return idx, h
 
-    def mark_dirty(self):
+    def mark_dirty(self, refit: bool = False):
         for k in self._dirty:
             self._dirty[k] = True
+            self._refit_next[k] = bool(refit)
 
     def set_option(self, name: str, value: int):
         self.options[name] = int(value)
@@ -210,7 +212,9 @@ def _ct_build_acceleration_structure(state, vertices: torch.Tensor, triangles: t
         raise RuntimeError("triangles must have dimensions (num_triangles, 3)")
     if not vertices.is_cuda or not triangles.is_cuda:
         raise RuntimeError("vertices/triangles must be CUDA tensors")
-    state.mark_dirty()
+    # rebuild == 0 is the reference's OPTIX_BUILD_OPERATION_UPDATE (trace_surfels.cpp:63-73: same topology, new vertex positions): the
+    # structure is refitted (lrt_refit) when the next trace finds the number of Gaussians of the last full build, rebuilt otherwise
+    state.mark_dirty(refit=(int(rebuild) == 0))
     state.handle(vertices.device)      # create the per-device state eagerly (errors surface here)
 
 
@@ -234,7 +238,9 @@ def _ct_build_from_gaussians(state, means3D, scales, rotations, opacities, scale
             # refit_interval = K > 0: K refits (same primitive order and tree topology, new records and boxes: ~0.4x the cost)
             # between full builds of an unchanged number of Gaussians; 0 = rebuild every time, like the reference
             since = state._since_full.get(idx)
-            if state.refit_interval > 0 and since is not None and since < state.refit_interval and state._full_P.get(idx) == P:
+            can_refit = since is not None and state._full_P.get(idx) == P and P > 0
+            asked = state._refit_next.pop(idx, False)
+            if can_refit and (asked or (state.refit_interval > 0 and since < state.refit_interval)):
                 _capi.check(state._lib.lrt_refit(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
                                                  float(scale_modifier), _stream_ptr()), "lrt_refit")
                 state._since_full[idx] = since + 1

@@ -1,8 +1,9 @@
 """MI355X-native drop-in for the reference's ``diff_lidar_tracer`` package
 (DLT/diff_lidar_tracer/__init__.py:1-219): ``Tracer`` (nn.Module) and
 ``TracingSettings`` with the same constructor, method names, argument order,
-return tuple and error behaviour.  The native half is ``_C`` (ctypes on
-liblrt_hip.so) instead of a pybind11/OptiX module.
+return tuple and error behaviour.  The native half is ``_C``: the pybind11 torch
+extension ``_C_ext`` (csrc/lrt_torch_ext.cpp) on liblrt_hip.so's C ABI, with a
+ctypes binding of the same ABI as fallback -- instead of a pybind11/OptiX module.
 """
 from __future__ import annotations
 

@@ -89,12 +89,14 @@ class HipBackend:
         e = torch.empty(0, device=means.device)
         out, _, accum = self._C.trace_surfels(self.state, True, ray_o, ray_d, e, bg, means, shs, deg, e, opacities,
                                               scales, mod, rotations, e, e, e, e, False, False)
+        self.last_serial = self.state.last_serial      # identifies the hit record this forward left in the library state
         return out, accum
 
-    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0, grads_out=None):
+    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0, grads_out=None, forward_serial=None):
         e = torch.empty(0, device=means.device)
         g = self._C.trace_surfels_backward(self.state, ray_o, ray_d, e, bg, means, shs, deg, e, opacities, scales,
-                                           mod, rotations, e, e, e, e, False, False, out, None, dL, grads_out=grads_out)
+                                           mod, rotations, e, e, e, e, False, False, out, None, dL, grads_out=grads_out,
+                                           forward_serial=forward_serial)
         return {"means": g[0], "shs": g[1], "opacities": g[3], "scales": g[4], "rotations": g[5]}
 
     def defer_errors(self, on: bool = True):
@@ -123,7 +125,7 @@ class HipBackend:
 class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
-    def __init__(self, backend=None, group=None, exchange: str = "auto"):
+    def __init__(self, backend=None, group=None, exchange: str = "sparse"):
         """exchange: "owner" = rows of touched Gaussians go to their owning rank (complete gradient on the owner only); "dense" = one
         all_reduce of the flat gradient buffer (replicated); "sparse" = all_gather of the touched rows (replicated); "auto" = sparse
         unless the ranks together touched more than `sparse_max_fraction` of the Gaussians, then dense."""
@@ -216,6 +218,25 @@ class ShardedTracer:
                            "results are incomplete on it.  forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
                            "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly)")
 
+    def check_replicas(self, tensors, what: str = "parameters"):
+        """The replicated training design has NO parameter synchronisation: every rank must draw the same random numbers
+        (``torch.manual_seed`` with one seed on all ranks before ``densify_and_split`` is ever reached) and must add the same
+        gradient rows.  This is the cheap guard: a checksum of `tensors` (sum of the values and of their squares, float64) is
+        all-reduced with MIN and MAX and every rank raises alike when the two differ.  One small collective + one host read; call
+        it every few hundred steps (training_step does, ``opt.replica_check_interval``)."""
+        if self.world == 1 and not self.force_collectives:
+            return
+        acc = []
+        for t in tensors:
+            x = t.detach().double().reshape(-1)
+            acc += [x.sum(), (x * x).sum(), torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)]
+        v = torch.stack(acc)
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group); dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not bool(torch.equal(lo, hi)):
+            raise RuntimeError(f"sharded tracer: the replicas' {what} have diverged (checksums differ between ranks): every rank must "
+                               "be seeded identically (torch.manual_seed) and run the same optimizer / densification code")
+
     @staticmethod
     def _backend_takes(fn, name: str) -> bool:
         """Capability of an injected backend, from its signature (a TypeError raised INSIDE the backend must not be mistaken for
@@ -246,6 +267,10 @@ class ShardedTracer:
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
         self._out_loc, self._accum_loc = out_loc, accum_loc
+        # what backward() needs of THIS forward: an autograd Function keeps it in its ctx (renderer._ShardedTrace), so that a second
+        # forward before loss.backward() -- an evaluation render, another frame -- cannot make the backward differentiate the wrong slab
+        self.last_ctx = {"slab": (a, b), "ro": self._ro, "rd": self._rd, "out_loc": out_loc, "accum_loc": accum_loc,
+                         "serial": getattr(self.backend, "last_serial", None)}
         if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
         # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
@@ -267,8 +292,12 @@ class ShardedTracer:
 
     # ---- backward ---------------------------------------------------------------------------------------------------------------
     def backward(self, means, scales, rotations, opacities, shs, deg, bg, dL_full, mod=1.0,
-                 reduce: bool = True) -> Dict[str, torch.Tensor]:
-        a, b = self._slab
+                 reduce: bool = True, fwd_ctx=None) -> Dict[str, torch.Tensor]:
+        """fwd_ctx: the `last_ctx` of the forward to differentiate (default: the most recent one).  When another forward has
+        replaced the library's hit record since, the local backward re-traces (forward_serial mismatch) -- same gradients."""
+        fc = fwd_ctx if fwd_ctx is not None else self.last_ctx
+        a, b = fc["slab"]
+        ro_, rd_, out_loc_, accum_loc_ = fc["ro"], fc["rd"], fc["out_loc"], fc["accum_loc"]
         dL = dL_full[:, a:b].contiguous()
         P = means.shape[0]; M = shs.shape[1]
         lay = getattr(self, "_layout", None)
@@ -276,14 +305,14 @@ class ShardedTracer:
             lay = self._layout = GradLayout(P, M, means.device)           # reused across steps: no per-step 240 MB allocation
         direct = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
         if self._backend_takes(self.backend.backward, "grads_out"):
-            self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
-                                  self._out_loc, dL, mod, grads_out=direct)      # kernels write straight into the flat buffer
+            kw = {"forward_serial": fc.get("serial")} if self._backend_takes(self.backend.backward, "forward_serial") else {}
+            self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg,
+                                  out_loc_, dL, mod, grads_out=direct, **kw)     # kernels write straight into the flat buffer
         else:                                                                     # backend without grads_out (test stand-ins)
-            g = self.backend.backward(self._ro, self._rd, means, scales, rotations, opacities, shs, deg, bg,
-                                      self._out_loc, dL, mod)
+            g = self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg, out_loc_, dL, mod)
             for k in direct:
                 direct[k].copy_(g[k].view_as(direct[k]))
-        lay.views["accum"].copy_(self._accum_loc)
+        lay.views["accum"].copy_(accum_loc_)
         self.last_exchange = None
         if reduce and (self.world > 1 or self.force_collectives):
             with self._Region(self, "gradient_exchange", lay.flat.device):

@@ -51,13 +51,14 @@ class _ShardedTrace(torch.autograd.Function):
         out, accum_loc = st.forward(ray_o.contiguous(), ray_d.contiguous(), a[0], a[1], a[2], a[3], a[4], int(deg), bg)
         accum_out.copy_(accum_loc.reshape(accum_out.shape))
         ctx.st, ctx.deg, ctx.bg, ctx.accum_out = st, int(deg), bg, accum_out
+        ctx.fwd = st.last_ctx          # this forward's slab, rays, local output and record serial (a later forward must not replace them)
         ctx.save_for_backward(*a)
         return out
 
     @staticmethod
     def backward(ctx, dL):
         means, scales, rotations, opacity, shs = ctx.saved_tensors
-        g = ctx.st.backward(means, scales, rotations, opacity, shs, ctx.deg, ctx.bg, dL.contiguous())
+        g = ctx.st.backward(means, scales, rotations, opacity, shs, ctx.deg, ctx.bg, dL.contiguous(), fwd_ctx=ctx.fwd)
         ctx.accum_out.copy_(g["accum"].reshape(ctx.accum_out.shape))
         # the views belong to a buffer the next step reuses: hand autograd its own copies
         return (None, None, None, g["means"].clone(), g["scales"].clone(), g["rotations"].clone(),

@@ -489,5 +489,10 @@ def training_step(scene: GaussianScene, frames: RangeFrames, frame, iteration: i
     loss.backward()
     with torch.no_grad():
         info = scene.optimize(opt, iteration, pkg["means3D"].grad, pkg["accum_gaussian_weight"])
+        # multi-GPU: the replicas are never synchronised (identical gradients + identical seeds keep them identical); verify it now and then
+        from . import renderer as _rnd
+        k_chk = int(getattr(opt, "replica_check_interval", 500))
+        if _rnd.sharded is not None and k_chk > 0 and iteration % k_chk == 0:
+            _rnd.sharded.check_replicas([p_ for g in scene.gaussians_assets for p_ in g._params().values()])
     return {"loss": loss.detach(), "depth": loss_depth.detach(), "intensity": loss_int.detach(), "raydrop": loss_drop.detach(),
             "chamfer": loss_cd.detach(), "densify": info, "points": sum(g._xyz.shape[0] for g in scene.gaussians_assets)}

@@ -36,7 +36,7 @@ setup(
     description="MI355X-native drop-in for the diff_lidar_tracer operator of LiDAR-RT (HIP, gfx950)",
     packages=find_packages(include=["lidar_rt_amd*", "diff_lidar_tracer*", "simple_knn*"]),
     py_modules=["chamfer_3D"],
-    package_data={"lidar_rt_amd": ["csrc/liblrt_hip.so", "csrc/*.hip", "csrc/*.inc", "csrc/*.h"]},
+    package_data={"lidar_rt_amd": ["csrc/liblrt_hip.so", "csrc/*.hip", "csrc/*.inc", "csrc/*.h", "csrc/*.cpp", "diff_lidar_tracer/_C_ext*.so"]},
     python_requires=">=3.9",
     cmdclass={"build_py": BuildPy, "develop": Develop},
 )

@@ -28,7 +28,8 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert set(_capi.EXPORTS) <= names
-    assert lib.lrt_abi_version() == 2
+    want = int(re.search(r"#define\s+LRT_ABI_VERSION\s+(\d+)", open(os.path.join(REPO, "include", "lrt.h")).read()).group(1))
+    assert lib.lrt_abi_version() == want == _capi.ABI_VERSION
 
 
 def test_error_reporting_without_a_gpu(lib):

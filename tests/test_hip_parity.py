@@ -1,4 +1,4 @@
-"""GPU parity tests: the HIP tracer (through the drop-in Tracer API -> ctypes -> C ABI) against the CPU oracle.
+"""GPU parity tests: the HIP tracer (through the drop-in Tracer API -> `_C` torch extension -> C ABI) against the CPU oracle.
 
 Tolerances (BASELINE.json north_star): outputs within 1e-4 relative, gradients within 1e-3 relative, fp32.
 "Relative" is taken element-wise against max(|ref|, 1e-3 * max|ref|) (values far below the tensor's scale are
@@ -81,6 +81,61 @@ def test_sh_tables_narrower_than_16(s10k, M, deg):
         assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 1e-3, k
     if (deg + 1) ** 2 < M:                                                     # coefficients above the active degree get no gradient
         assert not np.any(h["grads"]["shs"][:, (deg + 1) ** 2:])
+
+
+def test_sh_table_wider_than_a_wave_row(s10k):
+    """shs (P, 25, 3) -- a model allocated for SH degree 4 and traced at degree <= 3: a gradient row has 10 + 75 = 85 components, more
+    than the 64 lanes the bucketed reduction writes a row with, so the backward takes the sorted path (which zero-fills first); every
+    element of d_shs must be defined: the active coefficients match the oracle, the others are exactly zero."""
+    sc, o, d, dL = s10k
+    sc = dict(sc)
+    extra = np.random.default_rng(3).normal(0, 0.02, (sc["shs"].shape[0], 9, 3)).astype(np.float32)
+    sc["shs"] = np.ascontiguousarray(np.concatenate([sc["shs"], extra], axis=1))
+    fw, bw = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    assert rel_l2(h["out"], fw["out"]) < 1e-5 and frac_outside(h["out"], fw["out"], 1e-4) <= 1e-3
+    assert h["grads"]["shs"].shape == (sc["means"].shape[0], 25, 3)
+    assert np.all(np.isfinite(h["grads"]["shs"])) and not np.any(h["grads"]["shs"][:, 16:])
+    for k in GRADS:
+        assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 1e-3, k
+
+
+def test_build_acceleration_structure_rebuild_0_refits(s10k):
+    """`build_acceleration_structure(state, vertices, triangles, rebuild=0)` is the reference's OPTIX_BUILD_OPERATION_UPDATE
+    (trace_surfels.cpp:63-73): the next trace of an unchanged number of Gaussians refits the LBVH (lrt_refit) instead of
+    rebuilding it; results equal those of a rebuild; a changed P falls back to a full build."""
+    from lidar_rt_amd.diff_lidar_tracer import _C
+    from tests.hip_util import settings, DEFAULT_OPTS
+    sc, o, d, dL = s10k
+    r = np.random.default_rng(9)
+    tr = Tracer()
+    for k, v in DEFAULT_OPTS.items():
+        tr.optix_context.set_option(k, v)
+    ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")
+    vtx = torch.zeros((4, 3), device="cuda:0"); tri = torch.zeros((2, 3), dtype=torch.int32, device="cuda:0")
+
+    def trace(cur, rebuild):
+        t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in cur.items()}
+        tr.build_acceleration_structure(vtx, tri, rebuild=rebuild)
+        out, acc = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"],
+                      scales=t["scales"], rotations=t["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+        out.backward(torch.as_tensor(dL, device="cuda:0"))
+        return out.detach().cpu().numpy(), {k: t[k].grad.cpu().numpy() for k in GRADS}
+
+    since = lambda: dict(tr.optix_context._since_full)[0]
+    trace(sc, 1)
+    assert since() == 0
+    moved = dict(sc); moved["means"] = (sc["means"] + 0.03 * r.normal(size=sc["means"].shape)).astype(np.float32)
+    out, g = trace(moved, 0)
+    assert since() == 1                                                        # a refit, not a build
+    ref = run_hip(moved, o, d, 3, scenes.BG_DEFAULT, dL)
+    assert rel_l2(out, ref["out"]) < 1e-6
+    for k in GRADS:
+        assert rel_l2(g[k], ref["grads"][k]) < 1e-5, k
+    fewer = {k: np.ascontiguousarray(v[:-7]) for k, v in moved.items()}       # P changed: rebuild = 0 cannot update, a full build runs
+    out2, _ = trace(fewer, 0)
+    ref2 = run_hip(fewer, o, d, 3, scenes.BG_DEFAULT, dL)
+    assert rel_l2(out2, ref2["out"]) < 1e-6
 
 
 def test_side_stream(s10k):
