@@ -84,6 +84,7 @@ struct lrt_state {
     int tile_w_log2;
     RsSorter sort_build, sort_bwd; int own_sort;     // radix sorts: 2 (default) = own onesweep (lrt_radix.inc) for builds of >= 131072 primitives and for backward sorts below 1 M keys; 1 = own for both; 0 = rocPRIM
     int n_nodes, n_leaves;
+    int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
     // composited-hit record (forward with training=1 -> replay backward)
@@ -457,6 +458,32 @@ static int tree_layout(int P, int* n_leaves, int* n_levels, int cnt[LRT_MAX_LEVE
     return o;   // total nodes
 }
 
+// Records + tree of `Pk` sorted slots (order = st->vals_b): the fused launch pair, or the level-by-level kernels of rounds 1-3.
+static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, const float* scales, const float* rots, const float* opac, float mod,
+                                   const float4* pack, const unsigned* kept_ptr, bool records, hipStream_t stream, int* total_out, int* nl_out)
+{
+    const int TB = 256;
+    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
+    const int total = tree_layout(Pk, &nl, &L, cnt, off);
+    if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
+    *total_out = total; *nl_out = nl;
+    if (st->fused_tree && records && Pk > 0) {
+        TreeLayout lay; memset(&lay, 0, sizeof(lay));
+        lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
+        const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
+        hipLaunchKernelGGL(k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
+                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay);
+        if (L >= 4) hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
+        return LRT_OK;
+    }
+    if (records && Pk > 0)
+        hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, pack, kept_ptr);
+    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
+    for (int l = 2; l <= L; l++)
+        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
+    return LRT_OK;
+}
+
 static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
 {
     size_t need = (size_t)(P > 0 ? P : 1);
@@ -525,7 +552,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -604,6 +631,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "refine_ties")) { st->refine_ties = value ? 1 : 0; return LRT_OK; }   // 1 (default): hits closer than 2 ulp of t are ordered by their fp64 depth (needs the packed parameter lines of an unculled build); 0: by (t, gidx)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
+    if (!strcmp(name, "fused_tree")) { st->fused_tree = value ? 1 : 0; return LRT_OK; }   // 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
+    if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
@@ -900,6 +929,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     int Pk = P;                                                  // primitives that enter the LBVH
+    const unsigned* cone_kept = nullptr; const float4* pack_used = nullptr;
     if (P > 0) {
         unsigned* cone = nullptr;
         if (n_rays > 0) {                                        // cull against the cone around the given rays
@@ -938,7 +968,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         // count + 4096; the unused tail holds sentinel keys (sorted last, turned into padding by k_make_records) and the actual count
         // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
         unsigned keep_cap = (unsigned)P;
-        bool spec = false;
+        bool spec = false, hist_fused = false;
         if (cone && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
             unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess
                                                         : (st->cone_prev + st->cone_prev / 4 + 4096ull);
@@ -947,8 +977,17 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         }
         if (spec) HIPCHK(hipMemsetAsync(st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
         if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
-        else { int mb = (P + TB - 1) / TB; if (mb > 1024) mb = 1024;
-               hipLaunchKernelGGL(k_morton, dim3(mb), dim3(TB), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack); }
+        else {
+            // own onesweep next (decided below by the same rule) and fused_hist: k_morton counts the sort's digit histograms on the way
+            int pb_ = 1; while ((1ll << pb_) < (long long)P) pb_++;
+            int sb_ = pb_ + 4; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
+            hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && P >= LRT_BUILD_MERGE_LIMIT));
+            if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
+            const int mthreads = hist_fused ? 1024 : TB;
+            int mb = (P + mthreads - 1) / mthreads; if (mb > (hist_fused ? 256 : 1024)) mb = hist_fused ? 256 : 1024;
+            hipLaunchKernelGGL(k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
+                               hist_fused ? st->sort_build.hist : (unsigned*)nullptr, 63 - sb_, 63);
+        }
         if (cone) {
             HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             st->cone_prev_P = P;
@@ -975,19 +1014,16 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 int sb = pbits + 4; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
                 HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
                 uint64_t* kr = nullptr; uint32_t* vr = nullptr;
-                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr)));
+                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused)));
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
             } else
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
-            hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, (const float4*)pack, (const unsigned*)(spec ? cone + 10 : nullptr));
         }
+        cone_kept = spec ? cone + 10 : nullptr; pack_used = pack;
     }
-    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
-    int total = tree_layout(Pk, &nl, &L, cnt, off);
-    if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "%s: node capacity exceeded", fn);
-    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
-    for (int l = 2; l <= L; l++)    // one launch per level (a single-block loop over the small top levels measured slower)
-        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
+    int nl = 0, total = 0;
+    rc = launch_records_and_tree(st, Pk, means, scales, rots, opac, mod, (const float4*)pack_used, (const unsigned*)cone_kept, P > 0, stream, &total, &nl);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
     st->pack_valid = (P > 0 && !st->no_pack) ? 1 : 0;     // k_morton / k_morton_cull wrote the packed lines of every primitive that can be hit
@@ -1014,13 +1050,9 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
     const int TB = 256;
     float4* pack = st->no_pack ? nullptr : st->pack;
     if (pack) hipLaunchKernelGGL(k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack);
-    hipLaunchKernelGGL(k_make_records, dim3((P + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, P, st->vals_b, means, scales, rots, opac, mod,
-                       st->rec, st->aabb, (const float4*)pack, (const unsigned*)nullptr);
-    int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
-    tree_layout(P, &nl, &L, cnt, off);
-    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, P, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
-    for (int l = 2; l <= L; l++)
-        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
+    int nl = 0, total = 0;
+    int rc = launch_records_and_tree(st, P, means, scales, rots, opac, mod, (const float4*)pack, (const unsigned*)nullptr, true, stream, &total, &nl);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     st->mod = mod;
     st->pack_valid = pack ? 1 : 0;

@@ -277,6 +277,47 @@ def test_own_radix_sort_and_rocprim_give_the_same_results():
                 assert rel_l2(got["grads"][k], ref["grads"][k]) < 5e-7, (P, k)   # up to the float atomics of runs that span two waves (1.3e-7 seen)
 
 
+def _read_build(tr, which, n_bytes):
+    """Internal buffer of the current build (lrt_debug_read: 0 sorted order, 1 records, 2 SoA nodes)."""
+    import ctypes as C
+    st = tr.optix_context
+    _, h = st.handle(torch.device("cuda:0"))
+    buf = np.empty(n_bytes // 4, np.uint32)
+    st._lib.lrt_debug_read.restype = C.c_longlong
+    got = st._lib.lrt_debug_read(h, which, buf.ctypes.data_as(C.c_void_p), C.c_longlong(buf.nbytes), None)
+    return buf[:min(got, n_bytes) // 4]
+
+
+@pytest.mark.parametrize("P", [5, 64, 65, 513, 4097, 40_000, 300_000])
+def test_fused_tree_build_equals_the_level_by_level_one(P):
+    """k_make_tree (records + levels 1-3 per workgroup, boxes in LDS) + k_tree_top, and k_morton's fused digit histograms, against the
+    round-1..3 build (k_make_records, k_level1, one k_upper per level, k_rs_hist): same sorted order, bit-identical records and -- in
+    the 50 meaningful words of every node -- bit-identical trees, for tree depths 1 .. 6 and partial last nodes on every level."""
+    from tests.hip_util import DEFAULT_OPTS
+    sc = scenes.make_scene(P, seed=17 + P, radius_scale=0.5 if P > 100_000 else 0.25)
+    t = {k: torch.as_tensor(v, device="cuda:0") for k, v in sc.items()}
+    got = {}
+    for fused in (0, 1):
+        tr = Tracer()
+        for k, v in {**DEFAULT_OPTS, "own_sort": 1, "fused_tree": fused, "fused_hist": fused}.items():
+            tr.optix_context.set_option(k, v)
+        for rep in range(2):                                                   # twice: the histogram's zero-on-exit invariant must hold
+            tr.build_from_gaussians(t["means"], t["scales"], t["rotations"], t["opacities"])
+        torch.cuda.synchronize()
+        n_leaves = (P + 7) // 8
+        n_nodes, c = 0, n_leaves
+        while True:
+            c = max((c + 7) // 8, 1); n_nodes += c
+            if c == 1:
+                break
+        got[fused] = (_read_build(tr, 0, P * 4), _read_build(tr, 1, P * 64), _read_build(tr, 2, n_nodes * 256).reshape(-1, 64)[:, :50])
+        for k in ("fused_tree", "fused_hist"):
+            tr.optix_context.set_option(k, 1)
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+    np.testing.assert_array_equal(got[0][2], got[1][2])
+
+
 def test_bucketed_backward_against_the_sorted_one_on_awkward_index_layouts():
     """bwd_mode 3 (count / scatter / LDS sort per bucket / flat reduction) against bwd_mode 2 (key sort + segmented reduction) where the
     bucket machinery is stressed: Gaussian indices ordered by distance from the sensor (the near, heavily hit Gaussians share a few

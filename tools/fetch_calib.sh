@@ -10,11 +10,12 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA
   d=$OUT/$(echo $c | tr ' ' '_')
   timeout -k 5 120 rocprofv3 --pmc $c --output-format csv -d $d -o p -- $BIN > /dev/null 2> $d.err || echo "pass '$c' failed: $(tail -2 $d.err)"
 done
-python3 - <<PY
-import csv, glob, collections
+OUT=$OUT python3 - <<'PY'
+import csv, glob, collections, os
+OUT = os.environ["OUT"]
 known = {"cal_stream16": (1073.74, 0), "cal_gather<1, 8>": (67.11, 0), "cal_gather<4, 4>": (268.44, 0), "cal_gather<12, 12>": (805.31, 0), "cal_write16": (0, 1073.74), "cal_scatter16": (0, 67.11), "cal_atomic": (0, 16.78)}
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(OUT + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         c = acc[k][r["Counter_Name"]]; c[0] += float(r["Counter_Value"]); c[1] += 1
@@ -28,6 +29,6 @@ for k, (kr, kw) in known.items():
     f = lambda v: "-" if v is None else f"{v:.1f}"
     r = lambda v, kn: "-" if (v is None or not kn) else f"{v/kn:.2f}"
     lines.append(f"| `{k}` | {kr:.1f} | {kw:.1f} | {f(fm)} | {r(fm, kr)} | {f(wm)} | {r(wm, kw)} | {oth} |")
-open("$OUT/table.md", "w").write("\n".join(lines) + "\n")
-print("\n".join(lines)); print(open("$OUT/timing.txt").read())
+open(OUT + "/table.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines)); print(open(OUT + "/timing.txt").read())
 PY
