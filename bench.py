@@ -377,7 +377,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
                        "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
-                               + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (counts verified inside the step: one small device->host read)" if world > 1 else ""),
+                               + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (device-side: one pack launch, one all_gather, one apply launch; capacity overflows are flagged on the device and raised by the next step)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND},
             "roofline": roof,

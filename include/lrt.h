@@ -97,7 +97,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
  *   means/scales/rotations/opacities: the same parameter tensors given to lrt_build.
  *   out9: forward output; dL_dout9 (H,W,9): upstream gradient.
  *   d_means (P,3), d_shs (P,M,3), d_opacities (P), d_scales (P,2), d_rotations (P,4): OUTPUTS, every element is written (no need to
- *   clear them; the paths that accumulate zero-fill first).
+ *   clear them; the paths that accumulate zero-fill first).  Option "grads_prezeroed" = 1 reverses the contract: the caller hands over
+ *   tensors that ARE all-zero (it clears the rows of the previous step by list, lrt_xchg_apply with zero_only) and only the rows of
+ *   Gaussians with a hit are written -- no 232 MB of zero rows per call at 1 M Gaussians.
  * Stream order: the call does not wait for the forward.  If the forward's status (its composited-hit count) has not reached the
  * host yet, the work is enqueued anyway (bwd_mode 2: the sort sized from the last completed forward of the same image size, x 1.125 +
  * 64 k) and the kernels decide on the device between the replay and the re-tracing fallback (both enqueued; the one not needed
@@ -186,6 +188,23 @@ int lrt_grad_pack_touched(int device, int P, int M, int cap, const float* d_mean
                           const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx, unsigned* cnt, float* rows, void* stream);
 int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, float* d_means, float* d_scales,
                                float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
+
+/* Gathering exchange without a host read and with ONE launch per side (round 4; the training exchange of lidar_rt_amd/parallel.py).
+ * The Gaussian indices are cut into B = ceil(P / 1024) blocks; a message of lrt_xchg_msg_words(P, M, cap, with_rows) int32 words is
+ *   [off[B] | n[B] | idx[cap] | rows[cap][11 + 3M] (float)]: block b's touched Gaussians (accum > 0) at [off[b], off[b] + n[b]), ascending.
+ *   lrt_xchg_pack    lists and packs this rank's touched rows.  `counters`: 2 device words, both zero before the first call; `parity`
+ *                    alternates 0 / 1 from call to call (the kernel re-arms the word the NEXT call uses).  with_rows = 0: list only.
+ *   lrt_xchg_apply   msgs = N messages, `msg_words` apart (what an all-gather leaves).  zero_only = 0: the rows of list `rank` are
+ *                    cleared, then the lists 0 .. N-1 are added in that order, block by block (one workgroup owns a block: every
+ *                    replica forms bit-identical sums).  zero_only = 1: the rows of all lists are cleared (a caller that keeps its
+ *                    gradient buffers zero between steps: option "grads_prezeroed").  status (device, 1 + N words, may be NULL):
+ *                    [0] |= 1 when a list did not fit `cap` (its blocks are skipped: the step's sums are incomplete), [1 + r] = length
+ *                    of list r.  No call reads anything back: the caller looks at `status` when it has arrived. */
+long long lrt_xchg_msg_words(int P, int M, int cap, int with_rows);
+int lrt_xchg_pack(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations, const float* d_opacities,
+                  const float* d_shs, const float* accum, int32_t* msg, unsigned* counters, int parity, int with_rows, void* stream);
+int lrt_xchg_apply(int device, int P, int M, int N, int rank, int cap, const int32_t* msgs, long long msg_words, float* d_means, float* d_scales,
+                   float* d_rotations, float* d_opacities, float* d_shs, float* accum, unsigned* status, int zero_only, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_h
 EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_build_for_rays", "lrt_forward",
            "lrt_refit", "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_grad_gather", "lrt_grad_scatter_add",
            "lrt_owner_by_direction", "lrt_grad_pack_foreign", "lrt_grad_scatter_add_counted", "lrt_status_to_device",
-           "lrt_grad_pack_touched", "lrt_grad_zero_rows_counted",
+           "lrt_grad_pack_touched", "lrt_grad_zero_rows_counted", "lrt_xchg_msg_words", "lrt_xchg_pack", "lrt_xchg_apply",
            # include/lrt_chamfer.h
            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
            "lrt_chamfer_set_option",
@@ -74,6 +74,9 @@ def load():
     lib.lrt_status_to_device.restype = ci; lib.lrt_status_to_device.argtypes = [vp, vp, vp]
     lib.lrt_grad_pack_touched.restype = ci; lib.lrt_grad_pack_touched.argtypes = [ci, ci, ci, ci] + [vp] * 10
     lib.lrt_grad_zero_rows_counted.restype = ci; lib.lrt_grad_zero_rows_counted.argtypes = [ci, ci, ci, ci] + [vp] * 9
+    lib.lrt_xchg_msg_words.restype = C.c_longlong; lib.lrt_xchg_msg_words.argtypes = [ci, ci, ci, ci]
+    lib.lrt_xchg_pack.restype = ci; lib.lrt_xchg_pack.argtypes = [ci, ci, ci, ci] + [vp] * 8 + [ci, ci, vp]
+    lib.lrt_xchg_apply.restype = ci; lib.lrt_xchg_apply.argtypes = [ci, ci, ci, ci, ci, ci, vp, C.c_longlong] + [vp] * 7 + [ci, vp]
     lib.lrt_debug_read.restype = C.c_longlong; lib.lrt_debug_read.argtypes = [vp, ci, vp, C.c_longlong, vp]
     lib.lrt_set_option.restype = ci; lib.lrt_set_option.argtypes = [vp, C.c_char_p, ci]
     lib.lrt_get_option.restype = ci; lib.lrt_get_option.argtypes = [vp, C.c_char_p, C.POINTER(ci)]

@@ -70,6 +70,7 @@ struct lrt_state {
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
+    unsigned* tree_top; size_t tree_top_words;   // k_make_tree: ordered-uint boxes of the level-3 nodes (6 words each, self re-arming) + the ticket counter (last word)
     float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack, pack_valid, refine_ties;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 3 x 6 ordered-uint (min xyz, max xyz): read by this build / accumulated for the next / armed for the one after
     int bounds_sel, bounds_ready, lag_bounds;
@@ -84,6 +85,8 @@ struct lrt_state {
     int tile_w_log2;
     RsSorter sort_build, sort_bwd; int own_sort;     // radix sorts: 2 (default) = own onesweep (lrt_radix.inc) for builds of >= 131072 primitives and for backward sorts below 1 M keys; 1 = own for both; 0 = rocPRIM
     int n_nodes, n_leaves;
+    int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
+    int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
     int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
@@ -138,6 +141,7 @@ struct TraceParams {
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     float2* hit_wa;        // deferred-colour forward: per recorded hit (composite weight, unclamped op*G)
+    int prezeroed;         // backward: the gradient tensors are all-zero on entry (option grads_prezeroed): no zero rows are stored
     int fast_prep;         // backward: hit_wa / hit_pk hold the forward's alpha and colour of every recorded hit
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
@@ -403,6 +407,110 @@ __global__ void __launch_bounds__(256) k_list_foreign(int P, int rank, int cap, 
     if (slot < (unsigned)cap) idx[(size_t)d * cap + slot] = g;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Gathering exchange, round 4 (include/lrt.h: lrt_xchg_*): ONE launch packs a rank's touched rows, ONE launch applies all N received
+// lists -- deterministic without a host read and without one launch per list.  The Gaussian indices are cut into blocks of XB_G = 1024;
+// a message is  [off[B] | n[B] | idx[cap] | rows[cap][width]]  (B = ceil(P / 1024)): the entries of block b lie at [off[b], off[b] + n[b]),
+// in ascending index order (the blocks themselves land in the order of an atomic counter).  The receiver gives block b to ONE workgroup,
+// which clears its own rank's rows and then adds list 0, 1, .. N-1 with a barrier between lists: every replica forms the same sums in
+// the same order.  A list that did not fit its capacity raises status bit 1 (the affected blocks are skipped): the caller learns about
+// it lazily and raises on all ranks alike (every rank sees the same messages).
+#define XB_G 1024
+__device__ __forceinline__ float* grad_field_ptr(const GradFields& g, int gi, int e)
+{
+    int k = 0;
+    while (e >= g.w[k]) { e -= g.w[k]; k++; }
+    return g.f[k] + (size_t)gi * g.w[k] + e;
+}
+
+__global__ void __launch_bounds__(256) k_xchg_pack(int P, int B, int cap, int width, GradFields g, int32_t* __restrict__ msg, unsigned* __restrict__ counters, int parity, int with_rows)
+{
+    __shared__ unsigned s_c[4][4], s_off;
+    __shared__ int s_g[XB_G];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    if (b == 0 && tid == 0) counters[parity ^ 1] = 0u;                // re-arm the other counter for the next call
+    const float* accum = g.f[5];
+    bool t[4]; unsigned within[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gi = b * XB_G + j * 256 + tid;
+        t[j] = gi < P && accum[gi] > 0.f;
+        const unsigned long long m = __ballot(t[j]);
+        within[j] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_c[j][wv] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tot = 0u;
+        for (int i = 0; i < 16; i++) { const unsigned c = (&s_c[0][0])[i]; (&s_c[0][0])[i] = tot; tot += c; }
+        const unsigned off = tot ? atomicAdd(counters + parity, tot) : 0u;
+        s_off = off;
+        msg[b] = (int32_t)off; msg[B + b] = (int32_t)tot;
+        s_c[3][3] |= 0u;                                              // (keeps the prefix table; tot is recomputed below)
+    }
+    __syncthreads();
+    const unsigned off = s_off;
+    int32_t* idx = msg + 2 * (size_t)B;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (t[j]) {
+            const unsigned k = s_c[j][wv] + within[j];
+            const int gi = b * XB_G + j * 256 + tid;
+            s_g[k] = gi;
+            if (off + k < (unsigned)cap) idx[off + k] = gi;
+        }
+    if (!with_rows) return;
+    __syncthreads();
+    const unsigned n = (unsigned)msg[B + b];                          // written by thread 0 before the barrier above (same workgroup)
+    const unsigned n_fit = off >= (unsigned)cap ? 0u : min(n, (unsigned)cap - off);
+    float* rows = reinterpret_cast<float*>(idx + cap);
+    for (unsigned i = tid; i < n_fit * (unsigned)width; i += 256u) {
+        const unsigned k = i / (unsigned)width, e = i - k * (unsigned)width;
+        rows[(size_t)(off + k) * width + e] = *grad_field_ptr(g, s_g[k], (int)e);
+    }
+}
+
+// zero_only = 0: clear list `rank`'s rows, add lists 0 .. N-1 in order.  zero_only = 1: clear the rows of ALL lists (the caller keeps its
+// gradient buffers all-zero between steps: lrt option grads_prezeroed).  status[0] |= 1 on a capacity overflow, status[1 + r] = length of list r.
+__global__ void __launch_bounds__(256) k_xchg_apply(int P, int B, int N, int rank, int cap, int width, const int32_t* __restrict__ msgs, long long msg_words,
+                                                    GradFields g, unsigned* __restrict__ status, int zero_only)
+{
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (b == 0 && status && !zero_only) {                            // list lengths for the caller's capacity bookkeeping
+        for (int r = 0; r < N; r++) {
+            const int32_t* hdr = msgs + (size_t)r * msg_words;
+            unsigned s = 0u;
+            for (int i = tid; i < B; i += 256) s += (unsigned)hdr[B + i];
+            s = wave_sum_u(s);
+            __shared__ unsigned s_w[4];
+            if ((tid & 63) == 0) s_w[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) status[1 + r] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            __syncthreads();
+        }
+    }
+    bool ovf = false;
+    for (int r = 0; r < N; r++) {
+        const int32_t* hdr = msgs + (size_t)r * msg_words;
+        ovf = ovf || ((unsigned)hdr[b] + (unsigned)hdr[B + b] > (unsigned)cap);
+    }
+    if (ovf) { if (tid == 0 && status) atomicOr(status, 1u); if (!zero_only) return; }
+    for (int pass = zero_only ? 0 : -1; pass < N; pass++) {         // pass -1: clear the own list's rows; pass r: list r
+        const int r = pass < 0 ? rank : pass;
+        const int32_t* hdr = msgs + (size_t)r * msg_words;
+        const unsigned off = (unsigned)hdr[b];
+        const unsigned n = off >= (unsigned)cap ? 0u : min((unsigned)hdr[B + b], (unsigned)cap - off);
+        const int32_t* idx = hdr + 2 * (size_t)B;
+        const float* rows = reinterpret_cast<const float*>(idx + cap);
+        for (unsigned i = tid; i < n * (unsigned)width; i += 256u) {
+            const unsigned k = i / (unsigned)width, e = i - k * (unsigned)width;
+            float* d = grad_field_ptr(g, idx[off + k], (int)e);
+            if (pass < 0 || zero_only) *d = 0.f; else *d += rows[(size_t)(off + k) * width + e];
+        }
+        __syncthreads();                                             // two lists may hold the same Gaussian: list order = addition order
+    }
+}
+
 __global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (float)(ctrl[10] | ctrl[12]); }
 
 #include "lrt_near.inc"
@@ -472,8 +580,8 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
         hipLaunchKernelGGL(k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
-                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay);
-        if (L >= 4) hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
+                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top, st->tree_top + st->tree_top_words - 1);
+        if (st->fused_tree == 2 && L >= 4) hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
         return LRT_OK;
     }
     if (records && Pk > 0)
@@ -490,9 +598,9 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top};
     for (void* q : olds) (void)hipFree(q);
-    st->nodes_aos = nullptr; st->pack = nullptr;
+    st->nodes_aos = nullptr; st->pack = nullptr; st->tree_top = nullptr; st->tree_top_words = 0;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
@@ -511,6 +619,14 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     st->cap_nodes = (size_t)total + 16;
     HIPCHK(hipMalloc(&st->nodes, st->cap_nodes * LRT_NODE_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc(&st->nodes_aos, st->cap_nodes * LRT_NODE_FLOATS * sizeof(float)));
+    {   // level-3 node boxes of k_make_tree: (min xyz = ~0, max xyz = 0) per node, then the ticket counter = 0; the kernel re-arms them itself
+        const size_t n3 = cap / (8 * MT_THREADS) + 2;
+        std::vector<unsigned> init(n3 * 6 + 1, 0u);
+        for (size_t i = 0; i < n3; i++) for (int q = 0; q < 3; q++) init[i * 6 + q] = 0xffffffffu;
+        HIPCHK(hipMalloc(&st->tree_top, init.size() * sizeof(unsigned)));
+        HIPCHK(hipMemcpy(st->tree_top, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        st->tree_top_words = init.size();
+    }
     st->capP = cap;
     return LRT_OK;
 }
@@ -552,7 +668,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -581,7 +697,7 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone, st->tree_top};
     if (st->cone_host) { (void)hipHostFree(st->cone_host); (void)hipEventDestroy(st->cone_ev); }
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -631,7 +747,9 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "refine_ties")) { st->refine_ties = value ? 1 : 0; return LRT_OK; }   // 1 (default): hits closer than 2 ulp of t are ordered by their fp64 depth (needs the packed parameter lines of an unculled build); 0: by (t, gidx)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
-    if (!strcmp(name, "fused_tree")) { st->fused_tree = value ? 1 : 0; return LRT_OK; }   // 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
+    if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
+    if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
+    if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
@@ -824,6 +942,48 @@ int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned
     const int width = 11 + 3 * M;
     const long long per = (long long)cap * width;
     hipLaunchKernelGGL(k_grad_rows_multi<2>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, (float*)nullptr, -1);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+long long lrt_xchg_msg_words(int P, int M, int cap, int with_rows)
+{
+    const long long B = ((long long)P + XB_G - 1) / XB_G;
+    return 2 * B + (long long)cap + (with_rows ? (long long)cap * (11 + 3 * M) : 0);
+}
+
+static GradFields grad_fields(const float* d_means, const float* d_scales, const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int M)
+{
+    GradFields g; g.f[0] = const_cast<float*>(d_means); g.w[0] = 3; g.f[1] = const_cast<float*>(d_scales); g.w[1] = 2; g.f[2] = const_cast<float*>(d_rotations); g.w[2] = 4;
+    g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
+    return g;
+}
+
+int lrt_xchg_pack(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations, const float* d_opacities,
+                  const float* d_shs, const float* accum, int32_t* msg, unsigned* counters, int parity, int with_rows, void* stream_)
+{
+    if (P < 0 || M < 0 || cap < 1 || (parity != 0 && parity != 1)) LRT_FAIL(LRT_ERR_ARG, "lrt_xchg_pack: bad sizes");
+    if (!msg || !counters || (P > 0 && !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_xchg_pack: null pointer");
+    if (P == 0) return LRT_OK;
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_xchg_pack: cannot select HIP device %d", device);
+    const int B = (P + XB_G - 1) / XB_G;
+    hipLaunchKernelGGL(k_xchg_pack, dim3(B), dim3(256), 0, (hipStream_t)stream_, P, B, cap, 11 + 3 * M, grad_fields(d_means, d_scales, d_rotations, d_opacities, d_shs, accum, M),
+                       msg, counters, parity, with_rows ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return LRT_OK;
+}
+
+int lrt_xchg_apply(int device, int P, int M, int N, int rank, int cap, const int32_t* msgs, long long msg_words, float* d_means, float* d_scales,
+                   float* d_rotations, float* d_opacities, float* d_shs, float* accum, unsigned* status, int zero_only, void* stream_)
+{
+    if (P < 0 || M < 0 || N < 1 || rank < 0 || rank >= N || cap < 1 || msg_words < lrt_xchg_msg_words(P, M, cap, zero_only ? 0 : 1))
+        LRT_FAIL(LRT_ERR_ARG, "lrt_xchg_apply: bad sizes");
+    if (!msgs) LRT_FAIL(LRT_ERR_ARG, "lrt_xchg_apply: null pointer");
+    if (P == 0) return LRT_OK;
+    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_xchg_apply: cannot select HIP device %d", device);
+    const int B = (P + XB_G - 1) / XB_G;
+    hipLaunchKernelGGL(k_xchg_apply, dim3(B), dim3(256), 0, (hipStream_t)stream_, P, B, N, rank, cap, 11 + 3 * M, msgs, msg_words,
+                       grad_fields(d_means, d_scales, d_rotations, d_opacities, d_shs, accum, M), status, zero_only ? 1 : 0);
     HIPCHK(hipGetLastError());
     return LRT_OK;
 }
@@ -1137,6 +1297,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
     const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
+    bool fin_done = false;
     if (record) {
         if (HW > st->hit_rays_cap || st->hit_cap > st->hit_cap_alloc || st->key_avg > st->key_avg_alloc) {
             HIPCHK(hipStreamSynchronize(stream));
@@ -1245,7 +1406,9 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                 const int np_ = ((int)HW + 1) / 2;                                                          // two rays per wave
                 const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
                 ScopedTimer tmc(st, 3, stream);                                                             // the colour pass by itself (inside the forward region's timer)
-                hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp);
+                // the colour pass is the forward's epilogue as well (status words, hits beyond the record): no k_fwd_fin behind it (option fuse_fin)
+                hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp, st->fuse_fin ? st->ctrl : (unsigned*)nullptr, st->status_dev);
+                fin_done = st->fuse_fin != 0;
             } else { tp.ovf_list = nullptr; }
         }
         HIPCHK(hipGetLastError());
@@ -1256,7 +1419,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         if (HW > 0 && P > 0) hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
     }
     // epilogue: colours of the hits beyond the record (deferred colour), status words -> host-mapped block, sticky error bits
-    hipLaunchKernelGGL(k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
+    if (!fin_done) hipLaunchKernelGGL(k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->hit_ev, stream));
     st->fwd_pending = 1; st->last_stream = stream; st->bwdq_fresh = 1;
@@ -1285,7 +1448,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     // into the tensors, so they are cleared first; adjacent buffers (the Python binding and the sharded path hand over views of one
     // flat tensor) are filled at once
     auto zero_grads = [&]() -> int {
-        if (P <= 0) return LRT_OK;
+        if (P <= 0 || st->grads_prezeroed) return LRT_OK;
         struct Seg { float* p; size_t n; } seg[5] = {{d_means, (size_t)P * 3}, {d_shs, (size_t)P * M * 3}, {d_opac, (size_t)P},
                                                       {d_scales, (size_t)P * 2}, {d_rots, (size_t)P * 4}};
         for (int i = 1; i < 5; i++) for (int j = i; j > 0 && seg[j].p < seg[j - 1].p; j--) { Seg t = seg[j]; seg[j] = seg[j - 1]; seg[j - 1] = t; }
@@ -1301,7 +1464,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg;
     tp.means = means; tp.scales = scales; tp.rots = rots; tp.opac = opac; tp.mod = st->mod;
-    tp.out9_in = out9; tp.dL_dout = dL_dout9;
+    tp.out9_in = out9; tp.dL_dout = dL_dout9; tp.prezeroed = st->grads_prezeroed;
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
     // the re-tracing backward finds the rays with a quad closer than 0.2 m itself and replays them like k_fwd_near does (lrt_near.inc)
     if (st->near_list && (size_t)H * W <= st->near_cap) { tp.near_list = st->near_list + st->near_cap; tp.near_count = st->ctrl + 24; tp.near_done = st->ctrl + 25; tp.naos = (const float*)st->nodes_aos; }
@@ -1375,7 +1538,6 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                 }
                 hipLaunchKernelGGL(k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
                 hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
-                hipLaunchKernelGGL(k_bk_base, dim3(1), dim3(1024), 0, stream, tp);
                 if (tp.fast_prep) hipLaunchKernelGGL(k_bwd_prep2, dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
                 else hipLaunchKernelGGL((k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
                 hipLaunchKernelGGL(k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);

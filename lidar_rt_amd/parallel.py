@@ -158,6 +158,14 @@ class ShardedTracer:
         self.exchange_reruns = 0       # exchanges that had to run again with an exact capacity (statistics / tests)
         self.first_cap = None          # test hook: capacity of the first exchange of a size instead of the built-in guess
         self._bufs = {}                # reused message buffers of the exchanges, keyed by (what, shape)
+        # device path of the gathering exchange (lrt_xchg_*): no host read inside the step.  The gradient buffer is kept ALL-ZERO between
+        # steps (the rows of the previous step are cleared by list at the start of the next backward: `_prev_lists`), the library is told so
+        # (option grads_prezeroed) and writes only the rows of Gaussians with a hit -- no 232 MB of zero rows per step and rank at 1 M
+        self.prezero = os.environ.get("LRT_PREZERO", "1") == "1"
+        self._prev_lists = None        # (messages tensor, N, cap, msg_words) whose rows make up everything non-zero in the flat buffer
+        self._flat_dirty = True        # the flat buffer may hold anything: clear it whole before the next backward
+        self._xchg_par = 0
+        self._cap_hist = []            # list lengths of the last exchanges (capacity = 1.5 x their maximum + 4096)
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True):
@@ -206,6 +214,12 @@ class ShardedTracer:
             if ev is not None:
                 ev.synchronize()
             vals = host.reshape(-1).tolist()
+            if what == "exchange":                                   # [overflow flag, list length of every rank]: identical on all ranks
+                self._cap_hist = (self._cap_hist + [max(int(v) for v in vals[1:])])[-8:]
+                vals = vals[:1]
+                if vals[0] != 0:
+                    self.exchange_reruns += 1                        # (kept name) exchanges whose capacity was exceeded
+                    self._flat_dirty = True
             if any(v != 0 for v in vals) and bad is None:
                 bad = (what, vals)
         self._pending = still
@@ -216,7 +230,9 @@ class ShardedTracer:
             what, vals = bad
             raise LrtError(f"sharded tracer: a rank reported an overflow in an earlier step ({what}; per-rank words {vals}); that step's "
                            "results are incomplete on it.  forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
-                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly)")
+                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly); "
+                           "'exchange' word 1 = a rank touched more Gaussians than the speculated message capacity (1.5 x the recent maximum): "
+                           "that step's gradients are incomplete on every rank alike; the capacity has been raised")
 
     def check_replicas(self, tensors, what: str = "parameters"):
         """The replicated training design has NO parameter synchronisation: every rank must draw the same random numbers
@@ -303,7 +319,19 @@ class ShardedTracer:
         lay = getattr(self, "_layout", None)
         if lay is None or lay.P != P or lay.M != M or lay.flat.device != means.device:
             lay = self._layout = GradLayout(P, M, means.device)           # reused across steps: no per-step 240 MB allocation
+            self._prev_lists, self._flat_dirty = None, True
         direct = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
+        exchanging = reduce and (self.world > 1 or self.force_collectives)
+        pz = (self.prezero and lay.flat.is_cuda and hasattr(self.backend, "state") and (not exchanging or self.exchange == "sparse"))
+        if hasattr(self.backend, "state") and getattr(self, "_pz_set", None) != pz:
+            self.backend.state.set_option("grads_prezeroed", 1 if pz else 0); self._pz_set = pz
+        if pz:
+            if self._flat_dirty or self._prev_lists is None:
+                lay.flat.zero_()                                           # first step / after an error / after a dense exchange
+            else:
+                msgs, n_l, cap_l, words_l = self._prev_lists
+                self._xchg_apply(lay, msgs, n_l, 0, cap_l, words_l, None, zero_only=True)
+            self._flat_dirty = True                                        # until this step has left its lists behind
         if self._backend_takes(self.backend.backward, "grads_out"):
             kw = {"forward_serial": fc.get("serial")} if self._backend_takes(self.backend.backward, "forward_serial") else {}
             self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg,
@@ -312,13 +340,23 @@ class ShardedTracer:
             g = self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg, out_loc_, dL, mod)
             for k in direct:
                 direct[k].copy_(g[k].view_as(direct[k]))
-        lay.views["accum"].copy_(accum_loc_)
         self.last_exchange = None
+        if not exchanging:
+            if pz:                                             # leave this step's own list behind for the next step's clearing
+                cap = self._pz_cap(lay)
+                words = self._xchg_words(lay, cap, False)
+                msg = self._buf("pz_list", (words,), torch.int32, lay.flat.device)
+                self._xchg_pack(lay, msg, cap, accum_loc_, with_rows=False)
+                self._prev_lists, self._flat_dirty = (msg, 1, cap, words), False
+            return {**lay.views, "accum": accum_loc_}          # nothing to exchange: the forward's own accum tensor, no 4 P-byte copy
+        lay.views["accum"].copy_(accum_loc_)
         if reduce and (self.world > 1 or self.force_collectives):
             with self._Region(self, "gradient_exchange", lay.flat.device):
                 mode = self.exchange
                 if mode == "owner":
                     self._exchange_owner(lay, means)
+                elif mode == "sparse" and lay.flat.is_cuda and hasattr(self.backend, "state"):
+                    self._exchange_lists(lay, pz)
                 elif mode == "dense" or not self._exchange_sparse(lay):
                     dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
                     self.last_exchange = "dense"
@@ -501,6 +539,86 @@ class ShardedTracer:
                     col += k
         self._adapt_cap(biggest)
         self.last_exchange = "owner"
+
+    # ---- replicated gathering exchange, device path (lrt_xchg_*): no host read, one launch per side ---------------------------------
+    @staticmethod
+    def _xchg_words(lay: GradLayout, cap: int, with_rows: bool) -> int:
+        from . import _capi
+        return int(_capi.load().lrt_xchg_msg_words(lay.P, lay.M, int(cap), 1 if with_rows else 0))
+
+    def _pz_cap(self, lay: GradLayout) -> int:
+        """Capacity of a LIST-ONLY message (4 bytes per entry): every Gaussian fits, so this list can never overflow."""
+        return max(lay.P, 1)
+
+    def _xchg_counters(self, dev) -> torch.Tensor:
+        c = self._bufs.get(("xchg_counters", str(dev)))
+        if c is None:
+            c = self._bufs[("xchg_counters", str(dev))] = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._xchg_par = 0
+        return c
+
+    def _xchg_pack(self, lay: GradLayout, msg: torch.Tensor, cap: int, accum: torch.Tensor, with_rows: bool):
+        import ctypes as C
+        from . import _capi
+        v, p = lay.views, _capi.ptr
+        dev = lay.flat.device
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        cnt = self._xchg_counters(dev)
+        with torch.cuda.device(di):
+            _capi.check(_capi.load().lrt_xchg_pack(di, lay.P, lay.M, int(cap), p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]),
+                                                   p(accum), p(msg), p(cnt), self._xchg_par, 1 if with_rows else 0,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_xchg_pack")
+        self._xchg_par ^= 1
+
+    def _xchg_apply(self, lay: GradLayout, msgs: torch.Tensor, n_lists: int, rank: int, cap: int, words: int, status, zero_only: bool):
+        import ctypes as C
+        from . import _capi
+        v, p = lay.views, _capi.ptr
+        dev = lay.flat.device
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(di):
+            _capi.check(_capi.load().lrt_xchg_apply(di, lay.P, lay.M, int(n_lists), int(rank), int(cap), p(msgs), C.c_longlong(int(words)), p(v["means"]), p(v["scales"]),
+                                                    p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]), p(status) if status is not None else None,
+                                                    1 if zero_only else 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_xchg_apply")
+
+    def _exchange_lists(self, lay: GradLayout, pz: bool):
+        """Replicated sums of the ranks' partial gradients, on the device from end to end: ONE launch lists and packs this rank's touched
+        rows into ``[off[B] | n[B] | idx[cap] | rows[cap][60]]`` (blocks of 1024 Gaussian indices), ONE all_gather moves the messages,
+        ONE launch clears this rank's own rows and adds every rank's list in rank order, block by block (a block of indices is owned by
+        one workgroup: bit-identical sums on all replicas).  Nothing is read back inside the step: the capacity is speculated (1.5 x the
+        largest list of the last 8 exchanges + 4096; the first exchange of a size: P / 4), the apply kernel raises a device flag when a
+        list did not fit (it skips the affected blocks), the flag and the list lengths travel to pinned memory asynchronously and the
+        NEXT forward's check() raises on all ranks alike (every rank saw the same messages) and raises the capacity."""
+        P, M, N, rank = lay.P, lay.M, self.world, self.rank
+        dev = lay.flat.device
+        key = ("lists", P, M, N)
+        if self._cap_key != key:
+            self._cap_key, self._cap_hist = key, []
+        if self.first_cap is not None and not self._cap_hist:
+            cap = int(self.first_cap)
+        elif self._cap_hist:
+            cap = max(self._cap_hist) + max(self._cap_hist) // 2 + 4096
+        else:
+            cap = max(P // 4, 65536)
+        cap = max(1, min(cap, max(P, 1)))
+        words = self._xchg_words(lay, cap, True)
+        msg = self._buf("xl_send", (words,), torch.int32, dev)
+        self._xchg_pack(lay, msg, cap, lay.views["accum"], with_rows=True)
+        if dist.get_backend(self.group) == "nccl":
+            recv = self._buf("xl_recv", (N * words,), torch.int32, dev)
+            dist.all_gather_into_tensor(recv, msg, group=self.group)
+        else:
+            parts = [torch.empty_like(msg) for _ in range(N)]
+            dist.all_gather(parts, msg, group=self.group)
+            recv = self._buf("xl_recv", (N * words,), torch.int32, dev)
+            recv.view(N, words).copy_(torch.stack(parts))
+        status = self._buf("xl_status", (1 + N,), torch.int32, dev)
+        status.zero_()
+        self._xchg_apply(lay, recv, N, rank, cap, words, status, zero_only=False)
+        self._remember("exchange", status)
+        if pz:
+            self._prev_lists, self._flat_dirty = (recv, N, cap, words), False
+        self.last_exchange = "sparse"
 
     # ---- replicated gathering exchange -------------------------------------------------------------------------------------------
     def _exchange_sparse(self, lay: GradLayout) -> bool:
