@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k"])
+    ap.add_argument("--workload", default="s1m", choices=["s1m", "s10k", "s200k", "waymo4m"], help="s1m = the headline (BASELINE configs[1]); waymo4m = the shape of "
+                    "configs[4] (4 M Gaussians, 64x2650 Waymo-style grid, ~4.5 ms step on one GPU): the size at which an 8-way azimuth split has enough work per rank")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. fwd_mode=0, bwd_mode=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="sparse", choices=["owner", "dense", "sparse", "auto"], help="gradient exchange for N > 1: sparse (default) = "
@@ -135,6 +136,11 @@ def main():
     ap.add_argument("--both-paths", dest="both_paths", action="store_true", default=True,
                     help="(default on one GPU) time the other --via path too, same window length, and report it beside `value` as `drop_in_path` / `direct_path`")
     ap.add_argument("--no-both-paths", dest="both_paths", action="store_false", help="time only the --via path")
+    ap.add_argument("--vary", action="store_true", help="add a second timed window in which the frame CHANGES from step to step like in training "
+                    "(train.py:125-148 draws another frame per iteration and the optimizer moves the parameters): 4 sensor poses (yawed / translated ray sets) "
+                    "in rotation and an Adam-sized perturbation of means / scales / opacities between steps.  Reported as `value_varying` BESIDE `value`: "
+                    "it shows what the temporal speculation (per-tile learned slab widths, Morton box of the previous build, speculated hit counts) is worth "
+                    "when consecutive frames differ")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     ap.add_argument("--no-stats-step", action="store_true", help="skip the one instrumented (untimed) step that collects the traversal counters: the profiling "
                     "scripts use it so that every kernel of the trace is a kernel of a regular step (the counters' k_fwd_cr4<.., true> instantiation is not)")
@@ -165,6 +171,8 @@ def main():
     # ---------------- synthetic workload (identical on every rank: seeded)
     if args.workload == "s1m":
         sc, ro, rd = scenes.s1m(); wl = "S1M: 1,000,000 Gaussians, 64x2048 KITTI-style sweep (BASELINE configs[1])"
+    elif args.workload == "waymo4m":
+        sc, ro, rd = scenes.waymo_dynamic_4m(); wl = "Waymo-dynamic shape: 4,000,000 Gaussians (background + posed actors), 64x2650 grid (BASELINE configs[4])"
     elif args.workload == "s200k":
         sc = scenes.make_scene(200_000, radius_scale=0.5); ro, rd = scenes.kitti_rays(32, 512); wl = "S200k (dev)"
     else:
@@ -264,6 +272,52 @@ def main():
         for _ in range(steps_run):
             ostep()
         barrier(); other = H * W * steps_run / (time.perf_counter() - t1)
+
+    # ---------------- the same step on a frame that changes every iteration (--vary)
+    varying = None
+    if args.vary and world == 1:
+        n_pose = 4
+        # the sensor stays inside the scene's empty cylinder (r < 2 m around the origin): a pose inside the clutter would make hundreds of
+        # "near rays" (a quad closer than 0.2 m: the literal K-buffer replay of lrt_near.inc), which is a property of that pose, not of a moving frame
+        yaws = [0.0, 0.35, -0.6, 1.3]; shifts = [(0.0, 0.0, 0.0), (0.30, -0.20, 0.05), (-0.35, 0.25, -0.03), (0.15, 0.40, 0.02)]
+        poses = []
+        for yw, sh in zip(yaws, shifts):
+            c_, s_ = float(np.cos(yw)), float(np.sin(yw))
+            R = torch.tensor([[c_, -s_, 0.0], [s_, c_, 0.0], [0.0, 0.0, 1.0]], device=dev)
+            poses.append(((ray_o + torch.tensor(sh, device=dev)).contiguous(), (ray_d @ R.T).contiguous()))
+        gen = torch.Generator(device=dev).manual_seed(7)
+        # Adam-sized steps (position lr 1.6e-4 x scene extent ~ 1e-2 m early in training, 1e-3 later; scaling lr 5e-3 on the log; opacity lr 5e-2 on the logit)
+        d_means = [1e-3 * torch.randn(t["means"].shape, device=dev, generator=gen) for _ in range(2)]
+        d_scale = [1.0 + 5e-3 * torch.randn(t["scales"].shape, device=dev, generator=gen) for _ in range(2)]
+        d_opac = [0.01 * torch.randn(t["opacities"].shape, device=dev, generator=gen) for _ in range(2)]
+        saved = {k: t[k].clone() for k in ("means", "scales", "opacities")}
+
+        def step_vary(i):
+            k_ = i & 1; sgn = 1.0 if (i >> 1) & 1 == 0 else -1.0                       # +a +b -a -b: the parameters stay where they were on average
+            t["means"].add_(d_means[k_], alpha=sgn)
+            t["scales"].mul_(d_scale[k_] if sgn > 0 else 1.0 / d_scale[k_])
+            t["opacities"].add_(d_opac[k_], alpha=sgn).clamp_(0.01, 0.99)
+            o_, d_ = poses[i % n_pose]
+            out_, _ = tr.forward(o_, d_, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step)
+            tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
+
+        for i in range(8):
+            step_vary(i)
+        st.enable_timing(True)
+        barrier(); tv = time.perf_counter()
+        for i in range(steps_run):
+            step_vary(i)
+        barrier(); el_v = time.perf_counter() - tv
+        ktv = st.get_timing(dev); st.enable_timing(False)
+        st.check(dev, wait=True)                                                      # an overflow of a speculated capacity would surface here
+        for k, v in saved.items():
+            t[k].copy_(v)
+        varying = {"value": H * W * steps_run / el_v, "unit": "rays/s", "steps": steps_run, "ms_per_step": 1e3 * el_v / steps_run,
+                   "poses": n_pose, "yaw_rad": yaws, "shift_m": shifts,
+                   "phase_ms": {k_: ktv[k_][0] / max(ktv[k_][1], 1) for k_ in ("build", "fwd", "bwd")},
+                   "parameter_step": "means += N(0, 1e-3 m), scales *= 1 + N(0, 5e-3), opacities += N(0, 0.01) per step (signs alternate); the three "
+                                     "in-place updates (~10 us of elementwise kernels) are inside the timed window"}
+        step()                                                                         # back on the fixed frame for the statistics step below
 
     # ---------------- one instrumented step for the traversal statistics (untimed)
     if not args.no_stats_step:
@@ -388,6 +442,8 @@ def main():
         }
         if other is not None:
             res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_run}
+        if varying is not None:
+            res["value_varying"] = varying
         if args.check_sum:
             res["checksums"] = cks
         if world == 1 and not args.no_cpu_baseline:

@@ -59,6 +59,8 @@ static thread_local char g_err[512] = "";
 
 #include "lrt_radix.inc"
 
+struct TreeLayout { int L; int cnt[LRT_MAX_LEVELS]; int off[LRT_MAX_LEVELS]; };     // levels 1 .. L of the implicit 8-wide tree: nodes per level, first node of a level
+
 struct lrt_state {
     int device;
     int P;               // primitives in the current BVH (-1: none)
@@ -70,7 +72,8 @@ struct lrt_state {
     uint64_t *keys_a, *keys_b;
     uint32_t *vals_a, *vals_b;
     void* sort_tmp; size_t sort_tmp_bytes;
-    unsigned* tree_top; size_t tree_top_words;   // k_make_tree: ordered-uint boxes of the level-3 nodes (6 words each, self re-arming) + the ticket counter (last word)
+    unsigned* tree_top; size_t tree_top_words;   // k_make_tree: ordered-uint boxes of the level-3 nodes (6 words each; re-armed by tree_finish_top)
+    int tree_pending; TreeLayout tree_lay;       // the levels >= 4 of the current tree are still to be written (by the next k_fwd_init, or k_tree_finish)
     float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack, pack_valid, refine_ties;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 3 x 6 ordered-uint (min xyz, max xyz): read by this build / accumulated for the next / armed for the one after
     int bounds_sel, bounds_ready, lag_bounds;
@@ -87,6 +90,7 @@ struct lrt_state {
     int n_nodes, n_leaves;
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
+    int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
     int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
     float* dbg; size_t dbg_floats;
@@ -423,50 +427,75 @@ __device__ __forceinline__ float* grad_field_ptr(const GradFields& g, int gi, in
     return g.f[k] + (size_t)gi * g.w[k] + e;
 }
 
+#define XB_PER_WG 4                       // exchange blocks per workgroup of k_xchg_pack: one returning atomic on the shared counter per 4096 Gaussians
 __global__ void __launch_bounds__(256) k_xchg_pack(int P, int B, int cap, int width, GradFields g, int32_t* __restrict__ msg, unsigned* __restrict__ counters, int parity, int with_rows)
 {
-    __shared__ unsigned s_c[4][4], s_off;
-    __shared__ int s_g[XB_G];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    if (b == 0 && tid == 0) counters[parity ^ 1] = 0u;                // re-arm the other counter for the next call
+    __shared__ unsigned s_c[XB_PER_WG][4][4], s_tot[XB_PER_WG], s_off[XB_PER_WG];
+    __shared__ int s_g[XB_PER_WG * XB_G];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) counters[parity ^ 1] = 0u;      // re-arm the other counter for the next call
     const float* accum = g.f[5];
-    bool t[4]; unsigned within[4];
+    bool t[XB_PER_WG][4]; unsigned within[XB_PER_WG][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int gi = b * XB_G + j * 256 + tid;
-        t[j] = gi < P && accum[gi] > 0.f;
-        const unsigned long long m = __ballot(t[j]);
-        within[j] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_c[j][wv] = (unsigned)__popcll(m);
+    for (int q = 0; q < XB_PER_WG; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = (blockIdx.x * XB_PER_WG + q) * XB_G + j * 256 + tid;
+            t[q][j] = gi < P && accum[gi] > 0.f;
+            const unsigned long long m = __ballot(t[q][j]);
+            within[q][j] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_c[q][j][wv] = (unsigned)__popcll(m);
+        }
+    __syncthreads();
+    if (tid < XB_PER_WG) {                                            // exclusive prefix inside every exchange block, its total
+        unsigned tot = 0u;
+        for (int i = 0; i < 16; i++) { const unsigned c = (&s_c[tid][0][0])[i]; (&s_c[tid][0][0])[i] = tot; tot += c; }
+        s_tot[tid] = tot;
     }
     __syncthreads();
     if (tid == 0) {
-        unsigned tot = 0u;
-        for (int i = 0; i < 16; i++) { const unsigned c = (&s_c[0][0])[i]; (&s_c[0][0])[i] = tot; tot += c; }
-        const unsigned off = tot ? atomicAdd(counters + parity, tot) : 0u;
-        s_off = off;
-        msg[b] = (int32_t)off; msg[B + b] = (int32_t)tot;
-        s_c[3][3] |= 0u;                                              // (keeps the prefix table; tot is recomputed below)
+        unsigned all = 0u;
+        for (int q = 0; q < XB_PER_WG; q++) all += s_tot[q];
+        unsigned off = all ? atomicAdd(counters + parity, all) : 0u;
+        for (int q = 0; q < XB_PER_WG; q++) {
+            const int b = blockIdx.x * XB_PER_WG + q;
+            s_off[q] = off;
+            if (b < B) { msg[b] = (int32_t)off; msg[B + b] = (int32_t)s_tot[q]; }
+            off += s_tot[q];
+        }
     }
     __syncthreads();
-    const unsigned off = s_off;
     int32_t* idx = msg + 2 * (size_t)B;
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (t[j]) {
-            const unsigned k = s_c[j][wv] + within[j];
-            const int gi = b * XB_G + j * 256 + tid;
-            s_g[k] = gi;
-            if (off + k < (unsigned)cap) idx[off + k] = gi;
-        }
+    for (int q = 0; q < XB_PER_WG; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (t[q][j]) {
+                const unsigned k = s_c[q][j][wv] + within[q][j];
+                const int gi = (blockIdx.x * XB_PER_WG + q) * XB_G + j * 256 + tid;
+                s_g[q * XB_G + k] = gi;
+                if (s_off[q] + k < (unsigned)cap) idx[s_off[q] + k] = gi;
+            }
     if (!with_rows) return;
     __syncthreads();
-    const unsigned n = (unsigned)msg[B + b];                          // written by thread 0 before the barrier above (same workgroup)
-    const unsigned n_fit = off >= (unsigned)cap ? 0u : min(n, (unsigned)cap - off);
     float* rows = reinterpret_cast<float*>(idx + cap);
-    for (unsigned i = tid; i < n_fit * (unsigned)width; i += 256u) {
-        const unsigned k = i / (unsigned)width, e = i - k * (unsigned)width;
-        rows[(size_t)(off + k) * width + e] = *grad_field_ptr(g, s_g[k], (int)e);
+    // one entry per wave and trip (four trips in flight), lane = column (the row of a Gaussian is 11 + 3M <= 64 floats for M <= 17; wider rows take more passes)
+    for (int c0 = 0; c0 < width; c0 += 64) {
+        const int e = c0 + lane;
+        int fk = 0, fe = e;
+        if (e < width) while (fe >= g.w[fk]) { fe -= g.w[fk]; fk++; }
+        const float* fbase = e < width ? g.f[fk] + fe : nullptr; const int fw = e < width ? g.w[fk] : 0;
+        for (int q = 0; q < XB_PER_WG; q++) {
+            const unsigned off = s_off[q], n = s_tot[q];
+            const unsigned n_fit = off >= (unsigned)cap ? 0u : min(n, (unsigned)cap - off);
+            for (unsigned k0 = wv; k0 < n_fit; k0 += 16u) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const unsigned k = k0 + 4u * u; v[u] = (e < width && k < n_fit) ? fbase[(size_t)s_g[q * XB_G + k] * fw] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const unsigned k = k0 + 4u * u; if (e < width && k < n_fit) rows[(size_t)(off + k) * width + e] = v[u]; }
+            }
+        }
     }
 }
 
@@ -495,19 +524,38 @@ __global__ void __launch_bounds__(256) k_xchg_apply(int P, int B, int N, int ran
         ovf = ovf || ((unsigned)hdr[b] + (unsigned)hdr[B + b] > (unsigned)cap);
     }
     if (ovf) { if (tid == 0 && status) atomicOr(status, 1u); if (!zero_only) return; }
-    for (int pass = zero_only ? 0 : -1; pass < N; pass++) {         // pass -1: clear the own list's rows; pass r: list r
-        const int r = pass < 0 ? rank : pass;
-        const int32_t* hdr = msgs + (size_t)r * msg_words;
-        const unsigned off = (unsigned)hdr[b];
-        const unsigned n = off >= (unsigned)cap ? 0u : min((unsigned)hdr[B + b], (unsigned)cap - off);
-        const int32_t* idx = hdr + 2 * (size_t)B;
-        const float* rows = reinterpret_cast<const float*>(idx + cap);
-        for (unsigned i = tid; i < n * (unsigned)width; i += 256u) {
-            const unsigned k = i / (unsigned)width, e = i - k * (unsigned)width;
-            float* d = grad_field_ptr(g, idx[off + k], (int)e);
-            if (pass < 0 || zero_only) *d = 0.f; else *d += rows[(size_t)(off + k) * width + e];
+    // one entry per wave and trip, lane = column: the lane's field pointer and row stride are fixed for the whole launch
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int c0 = 0; c0 < width; c0 += 64) {
+        const int e = c0 + lane;
+        int fk = 0, fe = e;
+        if (e < width) while (fe >= g.w[fk]) { fe -= g.w[fk]; fk++; }
+        float* fbase = e < width ? g.f[fk] + fe : nullptr; const int fw = e < width ? g.w[fk] : 0;
+        for (int pass = zero_only ? 0 : -1; pass < N; pass++) {     // pass -1: clear the own list's rows; pass r: list r
+            const int r = pass < 0 ? rank : pass;
+            const int32_t* hdr = msgs + (size_t)r * msg_words;
+            const unsigned off = (unsigned)hdr[b];
+            const unsigned n = off >= (unsigned)cap ? 0u : min((unsigned)hdr[B + b], (unsigned)cap - off);
+            const int32_t* idx = hdr + 2 * (size_t)B;
+            const float* rows = reinterpret_cast<const float*>(idx + cap);
+            for (unsigned k0 = wv; k0 < n; k0 += 16u) {               // four entries of this wave in flight: the index load -> row access chain is latency
+                int gi[4]; float rv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const unsigned k = k0 + 4u * u; gi[u] = k < n ? idx[off + k] : -1; }
+                if (e >= width) continue;
+                if (pass < 0 || zero_only) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (gi[u] >= 0) fbase[(size_t)gi[u] * fw] = 0.f;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const unsigned k = k0 + 4u * u; rv[u] = gi[u] >= 0 ? rows[(size_t)(off + k) * width + e] : 0.f; dv[u] = gi[u] >= 0 ? fbase[(size_t)gi[u] * fw] : 0.f; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (gi[u] >= 0) fbase[(size_t)gi[u] * fw] = dv[u] + rv[u];
+                }
+            }
+            if (!zero_only) __syncthreads();                         // two lists may hold the same Gaussian: list order = addition order
         }
-        __syncthreads();                                             // two lists may hold the same Gaussian: list order = addition order
+        if (c0 + 64 < width) __syncthreads();
     }
 }
 
@@ -526,10 +574,16 @@ __global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
 }
 
 // The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
+// tree_nodes != null: the LBVH of the build in front of this forward still lacks its levels >= 4 (k_make_tree only combined the level-3
+// boxes): the LAST workgroup of this launch writes them (tree_finish_top) -- every consumer of the tree runs behind this launch.
 __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
-                                                  unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag)
+                                                  unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag,
+                                                  float* tree_nodes, float* tree_naos, const TreeLayout lay, unsigned* tree_top)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    __shared__ float s_box[2 * 1536];
+    if (tree_nodes && blockIdx.x == gridDim.x - 1) { tree_finish_top(tree_nodes, tree_naos, lay, tree_top, (int)threadIdx.x, 256, s_box); if (gridDim.x > 1) return; }
+    const int nb_ = (tree_nodes && gridDim.x > 1) ? (int)gridDim.x - 1 : (int)gridDim.x;       // the finishing workgroup takes no share of the fills
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = nb_ * blockDim.x;
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
     // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
     // [24] near rays found by the re-tracing backward, [25] its finished workgroups
@@ -566,6 +620,14 @@ static int tree_layout(int P, int* n_leaves, int* n_levels, int cnt[LRT_MAX_LEVE
     return o;   // total nodes
 }
 
+// The top levels of the last fused build, if nobody has written them yet (a forward does it in its prologue launch).
+static void finish_tree_now(lrt_state* st, hipStream_t stream)
+{
+    if (!st->tree_pending) return;
+    hipLaunchKernelGGL(k_tree_finish, dim3(1), dim3(512), 0, stream, st->nodes, st->nodes_aos, st->tree_lay, st->tree_top);
+    st->tree_pending = 0;
+}
+
 // Records + tree of `Pk` sorted slots (order = st->vals_b): the fused launch pair, or the level-by-level kernels of rounds 1-3.
 static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, const float* scales, const float* rots, const float* opac, float mod,
                                    const float4* pack, const unsigned* kept_ptr, bool records, hipStream_t stream, int* total_out, int* nl_out)
@@ -575,13 +637,15 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
     const int total = tree_layout(Pk, &nl, &L, cnt, off);
     if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
     *total_out = total; *nl_out = nl;
+    finish_tree_now(st, stream);                                  // two builds in a row: `top` must be re-armed before this build combines into it
     if (st->fused_tree && records && Pk > 0) {
         TreeLayout lay; memset(&lay, 0, sizeof(lay));
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
         hipLaunchKernelGGL(k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
-                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top, st->tree_top + st->tree_top_words - 1);
+                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top);
         if (st->fused_tree == 2 && L >= 4) hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
+        else if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
         return LRT_OK;
     }
     if (records && Pk > 0)
@@ -600,7 +664,7 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     size_t cap = need + need / 8 + 1024;
     void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top};
     for (void* q : olds) (void)hipFree(q);
-    st->nodes_aos = nullptr; st->pack = nullptr; st->tree_top = nullptr; st->tree_top_words = 0;
+    st->nodes_aos = nullptr; st->pack = nullptr; st->tree_top = nullptr; st->tree_top_words = 0; st->tree_pending = 0;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
@@ -668,7 +732,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -748,6 +812,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
+    if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
@@ -967,7 +1032,7 @@ int lrt_xchg_pack(int device, int P, int M, int cap, const float* d_means, const
     if (P == 0) return LRT_OK;
     DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_xchg_pack: cannot select HIP device %d", device);
     const int B = (P + XB_G - 1) / XB_G;
-    hipLaunchKernelGGL(k_xchg_pack, dim3(B), dim3(256), 0, (hipStream_t)stream_, P, B, cap, 11 + 3 * M, grad_fields(d_means, d_scales, d_rotations, d_opacities, d_shs, accum, M),
+    hipLaunchKernelGGL(k_xchg_pack, dim3((B + XB_PER_WG - 1) / XB_PER_WG), dim3(256), 0, (hipStream_t)stream_, P, B, cap, 11 + 3 * M, grad_fields(d_means, d_scales, d_rotations, d_opacities, d_shs, accum, M),
                        msg, counters, parity, with_rows ? 1 : 0);
     HIPCHK(hipGetLastError());
     return LRT_OK;
@@ -1055,6 +1120,7 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
 {
     if (!st || st->P < 0) LRT_FAIL(LRT_ERR_STATE, "lrt_debug_read: nothing built");
     DeviceGuard dg(st->device);
+    finish_tree_now(st, (hipStream_t)stream_);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
     const void* src = nullptr; long long bytes = 0;
     switch (which) {
@@ -1104,10 +1170,13 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
                 st->cone_prev = st->cone_host[0];
             }
-            int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
-            hipLaunchKernelGGL(k_cone_init, dim3(1), dim3(64), 0, stream, cone);
-            hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
-            hipLaunchKernelGGL(k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
+            if (n_rays <= 131072) hipLaunchKernelGGL(k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone);
+            else {
+                int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
+                hipLaunchKernelGGL(k_cone_init, dim3(1), dim3(64), 0, stream, cone);
+                hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
+                hipLaunchKernelGGL(k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
+            }
         }
         // three bounds sets rotate: this build READS set s (the box of the previous build's centres -- or, on the first build of a state
         // and with option lag_bounds=0, the box k_bounds computes now), ACCUMULATES its own frame's box into set s+1 and ARMS set s+2
@@ -1140,7 +1209,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         else {
             // own onesweep next (decided below by the same rule) and fused_hist: k_morton counts the sort's digit histograms on the way
             int pb_ = 1; while ((1ll << pb_) < (long long)P) pb_++;
-            int sb_ = pb_ + 4; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
+            int sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
             hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && P >= LRT_BUILD_MERGE_LIMIT));
             if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
             const int mthreads = hist_fused ? 1024 : TB;
@@ -1168,10 +1237,10 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
             // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
-            int sort_bits = ((pbits + 4 + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
+            int sort_bits = ((pbits + st->morton_extra + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
             if (st->own_sort == 1 || (st->own_sort == 2 && Pk >= LRT_BUILD_MERGE_LIMIT)) {      // below the limit rocPRIM's merge sort needs fewer launches
                 // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
-                int sb = pbits + 4; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
+                int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
                 HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
                 uint64_t* kr = nullptr; uint32_t* vr = nullptr;
                 HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused)));
@@ -1279,8 +1348,11 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_fwd_init, dim3(blocks), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
-                           (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr));
+        const bool fin_tree = st->tree_pending != 0;
+        hipLaunchKernelGGL(k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
+                           (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr),
+                           fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top);
+        st->tree_pending = 0;
     }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
     tp.H = H; tp.W = W; tp.P = P; tp.M = M; tp.deg = deg;

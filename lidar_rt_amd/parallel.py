@@ -274,7 +274,7 @@ class ShardedTracer:
         self._slab = (a, b)
         self._ro = ray_o[:, a:b].contiguous(); self._rd = ray_d[:, a:b].contiguous()
         self._rays_full = (ray_o, ray_d)
-        cull = (self._ro, self._rd) if (self.world >= 3 and self.cull_build) else None
+        cull = (self._ro, self._rd) if self.cull_build else None
         if rebuild or cull is not None:                        # a ray-culled structure must be rebuilt for every ray set
             if self._backend_takes(self.backend.build, "cull_rays"):
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)

@@ -51,15 +51,16 @@ def frac_outside(a, b, rtol, floor=1e-3):
 # Quantitative parity: the HIP path against the fp32 oracle, bounded by k x the algorithm's own noise floor (the fp32 oracle
 # against the fp64 oracle on the same inputs), and the measured numbers written to gpurun_out/parity/<name>.json
 # (tools/collect_parity.py turns those files into profiles/r02_parity.json = BASELINE.md section 6).
-# Why k = 4 and not 1: two float32 implementations differ from EACH OTHER by about twice what one of them differs from the
+# Why k > 1: two float32 implementations differ from EACH OTHER by about twice what one of them differs from the
 # fp64 result, and the differences are threshold events, not rounding noise: hits less than ~2 ulp(t) apart change places
 # (only the colour channels see it), and a candidate on the edge of the reference's restart epsilon (t16 + 1e-5) is dropped by
 # one implementation and kept by the other.  tests/tools/outlier_arbiter.py arbitrates such rays hit by hit against a
 # brute-force float64 restatement of the raygen loop (27 of 40 examined rays: permutations of hits 0.3..5e-6 m apart, 13:
 # restart-epsilon edges); tests/tools/t_noise_probe.py measures the hit distance itself: 0.52 ulp median error for the HIP
 # path, 0.65 ulp for a float32 Moeller-Trumbore evaluation.  Measured ratios to the floor: 1..3.5 (profiles/r02_parity.json).
-FLOOR_K = 4.0            # on the fraction of elements beyond the tolerance (a count of events: robust)
-FLOOR_K_L2 = 8.0         # on the relative L2 error (dominated by the one or two largest events of an image: heavy-tailed)
+# Round 4: the gates follow the measurements (profiles/r03_parity.md, r04: largest ratios 2.1 on the fraction, 3.1 on L2) instead of 4 / 8.
+FLOOR_K = 2.5            # on the fraction of elements beyond the tolerance (a count of events: robust)
+FLOOR_K_L2 = 4.0         # on the relative L2 error (dominated by the one or two largest events of an image: heavy-tailed)
 OUT_TOL, GRAD_TOL = 1e-4, 1e-3            # BASELINE.json north_star: 1e-4 relative on rendered channels, 1e-3 on gradients
 
 

@@ -125,5 +125,5 @@ def test_prezeroed_backward_writes_only_touched_rows_and_sharded_tracer_keeps_th
         res[pz] = outs
     for a, b in zip(res[False], res[True]):
         for k in a:
-            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-9), k
+            assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(a[k].abs().max()), k   # runs that span two waves are summed with float atomics
             assert bool(((a[k] == 0) == (b[k] == 0)).all()), k                # untouched rows are exactly zero either way

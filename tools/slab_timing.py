@@ -13,35 +13,41 @@ t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
 H, W = ro.shape[:2]
 dL = torch.as_tensor(scenes.upstream_grad(H, W), device=dev)
 bg = torch.as_tensor(scenes.BG_DEFAULT, device=dev)
-be = HipBackend()
+from lidar_rt_amd.parallel import ShardedTracer
+tr = ShardedTracer()                              # one rank: what a rank of an N-way split does for ITS slab (build, forward, backward incl. the prezero protocol)
+be = tr.backend
 for kv in os.environ.get("LRT_OPTS", "").split(","):
     if kv: be.state.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 lay = GradLayout(1000000, 16, dev)
 grads = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
-for N in (1, 2, 4, 8):
+NS = tuple(int(x) for x in os.environ.get("SLAB_N", "1,2,4,8").split(","))
+for N in NS:
     for r in sorted({0, N // 2}):
         a, b = column_slab(W, r, N)
         o = torch.as_tensor(ro[:, a:b].copy(), device=dev); d = torch.as_tensor(rd[:, a:b].copy(), device=dev)
         g = dL[:, a:b].contiguous()
+        tr.cull_build = N >= int(os.environ.get("CULL_FROM", "3")) and os.environ.get("CULL", "0") == "1"
         be.state.enable_timing(True)
-        for it in range(6):
-            if it == 2: be.state.get_timing(dev)          # drop the warm-up samples
-            be.build(t["means"], t["scales"], t["rotations"], t["opacities"], cull_rays=(o, d) if (N >= 3 and os.environ.get("CULL", "0") == "1") else None)
-            out, acc = be.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
-            be.backward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, out, g, grads_out=grads)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        n_it, n_warm = 8, 3
+        for it in range(n_it):
+            if it == n_warm: be.state.get_timing(dev); ev[0].record()          # drop the warm-up samples
+            tr.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+            tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, g)
+        ev[1].record()
         torch.cuda.synchronize()
         tm = be.state.get_timing(dev)
         f = lambda k: tm[k][0] / max(tm[k][1], 1)
         kept = be.state.built_count(dev)
-        print(f"N={N} rank {r}: cols {b - a:4d}  kept {kept:7d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms")
+        print(f"N={N} rank {r}: cols {b - a:4d}  kept {kept:7d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms"
+              f"   whole per-rank step (events around build + forward + backward + list bookkeeping): {ev[0].elapsed_time(ev[1]) / (n_it - n_warm):.3f} ms")
 
 # ---- local cost of the owner-based gradient exchange for one rank (owner map + listing / packing of the foreign rows), and how
 # many rows a rank would send: the network leg itself cannot be measured on one GPU
 import ctypes as C
 from lidar_rt_amd import _capi
-from lidar_rt_amd.parallel import ShardedTracer
 lib = _capi.load(); p = _capi.ptr
-for N in (2, 4, 8):
+for N in ((2, 4, 8) if os.environ.get("SLAB_OWNER", "1") == "1" else ()):
     st = ShardedTracer.__new__(ShardedTracer); st.world = N; st.rank = 0
     st._rays_full = (torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev))
     a, b = column_slab(W, 0, N)
