@@ -161,7 +161,7 @@ class ShardedTracer:
         # device path of the gathering exchange (lrt_xchg_*): no host read inside the step.  The gradient buffer is kept ALL-ZERO between
         # steps (the rows of the previous step are cleared by list at the start of the next backward: `_prev_lists`), the library is told so
         # (option grads_prezeroed) and writes only the rows of Gaussians with a hit -- no 232 MB of zero rows per step and rank at 1 M
-        self.prezero = os.environ.get("LRT_PREZERO", "1") == "1"
+        self.prezero = os.environ.get("LRT_PREZERO", "1") != "0"
         self._prev_lists = None        # (messages tensor, N, cap, msg_words) whose rows make up everything non-zero in the flat buffer
         self._flat_dirty = True        # the flat buffer may hold anything: clear it whole before the next backward
         self._xchg_par = 0
@@ -322,7 +322,11 @@ class ShardedTracer:
             self._prev_lists, self._flat_dirty = None, True
         direct = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
         exchanging = reduce and (self.world > 1 or self.force_collectives)
-        pz = (self.prezero and lay.flat.is_cuda and hasattr(self.backend, "state") and (not exchanging or self.exchange == "sparse"))
+        # measured on S1M (profiles/r04_summary.md): a single rank gains nothing (zero rows inside k_bk_sort 37 us against list + clear-by-list
+        # 25 us plus two launches), a rank of an 8-way split saves the 45 us its dense zero rows cost -- so the protocol runs with the exchange only
+        pz = (self.prezero and lay.flat.is_cuda and hasattr(self.backend, "state") and exchanging and self.exchange == "sparse")
+        if os.environ.get("LRT_PREZERO", "") == "force":                  # tools/slab_timing.py: one process plays a rank of an N-way split
+            pz = lay.flat.is_cuda and hasattr(self.backend, "state") and (not exchanging or self.exchange == "sparse")
         if hasattr(self.backend, "state") and getattr(self, "_pz_set", None) != pz:
             self.backend.state.set_option("grads_prezeroed", 1 if pz else 0); self._pz_set = pz
         if pz:

@@ -113,8 +113,10 @@ def test_prezeroed_backward_writes_only_touched_rows_and_sharded_tracer_keeps_th
     bg = torch.as_tensor(scenes.BG_DEFAULT, device=DEV)
     H, W = ro.shape[:2]
     res = {}
+    import os
     for pz in (False, True):
-        tr = ShardedTracer(); tr.prezero = pz
+        os.environ["LRT_PREZERO"] = "force" if pz else "0"              # "force": the protocol without an exchange (what tools/slab_timing.py measures)
+        tr = ShardedTracer()
         outs = []
         for step in range(3):
             dL = torch.as_tensor(scenes.upstream_grad(H, W, seed=step), device=DEV)
@@ -123,6 +125,7 @@ def test_prezeroed_backward_writes_only_touched_rows_and_sharded_tracer_keeps_th
             g = tr.backward(mv["means"], mv["scales"], mv["rotations"], mv["opacities"], mv["shs"], 3, bg, dL)
             outs.append({k: v.clone() for k, v in g.items()})
         res[pz] = outs
+    os.environ.pop("LRT_PREZERO", None)
     for a, b in zip(res[False], res[True]):
         for k in a:
             assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(a[k].abs().max()), k   # runs that span two waves are summed with float atomics

@@ -2,6 +2,7 @@
 """Developer tool: per-rank compute time of an N-way azimuth split, measured on ONE GPU by tracing a single slab
 (rank 0's columns) of the S1M frame: build / forward / backward HIP-event times for N = 1, 2, 4, 8."""
 import os, sys
+os.environ.setdefault("LRT_PREZERO", "force")      # a rank of a split keeps its gradient buffer zero by list (what the exchange path does)
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes
