@@ -141,6 +141,9 @@ def main():
                     "in rotation and an Adam-sized perturbation of means / scales / opacities between steps.  Reported as `value_varying` BESIDE `value`: "
                     "it shows what the temporal speculation (per-tile learned slab widths, Morton box of the previous build, speculated hit counts) is worth "
                     "when consecutive frames differ")
+    ap.add_argument("--graph", action="store_true", help="library option graph=1: every API call's launch sequence is replayed from an instantiated HIP graph (one "
+                    "graph launch per lrt_build / lrt_forward / lrt_backward).  The step then runs on a side stream (the legacy default stream cannot be captured) and "
+                    "without the library's HIP-event timers (phase_ms / roofline per-kernel times are null).  What it buys is host launch time: S10k is launch-bound")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
     ap.add_argument("--no-stats-step", action="store_true", help="skip the one instrumented (untimed) step that collects the traversal counters: the profiling "
                     "scripts use it so that every kernel of the trace is a kernel of a regular step (the counters' k_fwd_cr4<.., true> instantiation is not)")
@@ -193,6 +196,11 @@ def main():
         k_, v_ = kv.split("=")
         st.set_option(k_, int(v_))
     st.refit_interval = max(args.refit_every, 0)
+    if args.graph:
+        st.set_option("graph", 1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)                                   # everything below is enqueued on the side stream
 
     def step_direct():
         out, _ = tr.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg,
@@ -246,7 +254,7 @@ def main():
         if world > 1:
             tr_ = torch.tensor([reps], dtype=torch.int64, device=dev); dist.all_reduce(tr_, op=dist.ReduceOp.MAX); reps = int(tr_.item())
     steps_run = args.steps * reps
-    st.enable_timing(True)
+    st.enable_timing(not args.graph)                                  # the library's timers record events between kernels: not inside a graph
     tr.enable_phase_timing(True)
     barrier()
     t0 = time.perf_counter()
@@ -433,7 +441,8 @@ def main():
                        "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
                                + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (device-side: one pack launch, one all_gather, one apply launch; capacity overflows are flagged on the device and raised by the next step)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
-                       "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND},
+                       "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND,
+                       "hip_graph": ({"replays": st.get_option("graph_hits", dev), "instantiated": st.get_option("graph_captures", dev)} if args.graph else None)},
             "roofline": roof,
             # per-phase GPU time per step on rank 0 (HIP events): LBVH build / forward trace / backward; N > 1: + slab all_gather and
             # gradient exchange (torch events around the collectives and their pack / unpack kernels)

@@ -24,6 +24,8 @@
 #include <cstring>
 
 #include <vector>
+#include <tuple>
+#include <utility>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -57,6 +59,102 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     LRT_FAIL(LRT_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
+// ---------------------------------------------------------------------------------------------------
+// Launch recorder (option "graph", round 4).  The step is stream-ordered and allocation-free after warm-up, so the launch sequence of an
+// API call (lrt_build: 5 launches, lrt_forward: 4, lrt_backward: 6-7) can be replayed from a HIP graph: one graph launch instead of a
+// launch per kernel (S10k is launch-bound: 25 launches x ~7 us).  Instead of capturing a call and hoping that its host-side bookkeeping
+// can be skipped on replay, EVERY call runs its host logic as usual while its stream operations are RECORDED (kernel, grid, a copy of the
+// arguments); at the end of the call the recorded sequence is fingerprinted: a known fingerprint launches the instantiated graph, an
+// unknown one is issued under stream capture once, instantiated and kept (LRU of 16 per state).  Host state never diverges from the
+// eager path, and a change of any launch argument (a new tensor address, a grown capacity) simply is another fingerprint.
+struct LrtRecOp {
+    int kind;                                    // 0 kernel, 1 memset, 2 memcpy
+    const void* fn; dim3 grid, block; size_t shm;
+    std::vector<unsigned char> blob; std::vector<size_t> arg_off;      // kernel arguments, copied
+    void* dst; const void* src; int value; size_t bytes; hipMemcpyKind mk;
+};
+struct LrtRec {
+    bool on = false;                             // recording (graph mode and nothing in this call that cannot be recorded)
+    std::vector<LrtRecOp> ops;
+    struct Entry { uint64_t fp; size_t n_ops; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
+    std::vector<Entry> cache; uint64_t clock = 0; unsigned long long hits = 0, captures = 0;
+};
+static inline uint64_t lrt_fnv(uint64_t h, const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+
+template <typename... KArgs, typename... Args>
+static inline void lrt_launch(LrtRec* rec, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shm, hipStream_t stream, Args&&... args)
+{
+    if (!rec || !rec->on) { hipLaunchKernelGGL(kernel, grid, block, shm, stream, std::forward<Args>(args)...); return; }
+    LrtRecOp op; op.kind = 0; op.fn = reinterpret_cast<const void*>(kernel); op.grid = grid; op.block = block; op.shm = shm;
+    std::tuple<typename std::decay<KArgs>::type...> tup(static_cast<typename std::decay<KArgs>::type>(args)...);
+    // the arguments, each at an offset aligned like in the tuple's element (copied bytewise: kernel arguments are trivially copyable)
+    size_t off = 0;
+    auto put = [&](const auto& a) { const size_t al = alignof(std::decay_t<decltype(a)>) < 16 ? 16 : alignof(std::decay_t<decltype(a)>); off = (off + al - 1) / al * al;
+                                     op.arg_off.push_back(off); op.blob.resize(off + sizeof(a)); memcpy(op.blob.data() + off, &a, sizeof(a)); off += sizeof(a); };
+    std::apply([&](const auto&... a) { (put(a), ...); }, tup);
+    rec->ops.push_back(std::move(op));
+}
+static inline hipError_t lrt_memset_async(LrtRec* rec, void* dst, int value, size_t bytes, hipStream_t stream)
+{
+    if (!rec || !rec->on) return hipMemsetAsync(dst, value, bytes, stream);
+    LrtRecOp op; op.kind = 1; op.dst = dst; op.value = value; op.bytes = bytes; rec->ops.push_back(std::move(op)); return hipSuccess;
+}
+static inline hipError_t lrt_memcpy_async(LrtRec* rec, void* dst, const void* src, size_t bytes, hipMemcpyKind mk, hipStream_t stream)
+{
+    if (!rec || !rec->on) return hipMemcpyAsync(dst, src, bytes, mk, stream);
+    LrtRecOp op; op.kind = 2; op.dst = dst; op.src = src; op.bytes = bytes; op.mk = mk; rec->ops.push_back(std::move(op)); return hipSuccess;
+}
+static hipError_t lrt_rec_issue(LrtRec* rec, hipStream_t stream)        // the recorded operations, in order, onto `stream`
+{
+    for (auto& op : rec->ops) {
+        hipError_t e = hipSuccess;
+        if (op.kind == 0) {
+            std::vector<void*> argv(op.arg_off.size());
+            for (size_t i = 0; i < argv.size(); i++) argv[i] = op.blob.data() + op.arg_off[i];
+            e = hipLaunchKernel(op.fn, op.grid, op.block, argv.data(), op.shm, stream);
+        } else if (op.kind == 1) e = hipMemsetAsync(op.dst, op.value, op.bytes, stream);
+        else e = hipMemcpyAsync(op.dst, op.src, op.bytes, op.mk, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+// End of a recorded section: launch the graph of this exact operation sequence (instantiating it on first sight).  Returns hipSuccess with
+// nothing to do when the recorder is off (everything was issued eagerly).
+static hipError_t lrt_rec_flush(LrtRec* rec, hipStream_t stream)
+{
+    if (!rec || !rec->on) return hipSuccess;
+    rec->on = false;
+    if (rec->ops.empty()) return hipSuccess;
+    uint64_t fp = 1469598103934665603ull;
+    for (auto& op : rec->ops) {
+        fp = lrt_fnv(fp, &op.kind, sizeof(op.kind));
+        if (op.kind == 0) { fp = lrt_fnv(fp, &op.fn, sizeof(op.fn)); fp = lrt_fnv(fp, &op.grid, sizeof(op.grid)); fp = lrt_fnv(fp, &op.block, sizeof(op.block)); fp = lrt_fnv(fp, &op.shm, sizeof(op.shm));
+                            for (size_t i = 0; i < op.arg_off.size(); i++) { const size_t b = op.arg_off[i], e = i + 1 < op.arg_off.size() ? op.arg_off[i + 1] : op.blob.size(); (void)e; }
+                            fp = lrt_fnv(fp, op.blob.data(), op.blob.size()); }
+        else { fp = lrt_fnv(fp, &op.dst, sizeof(op.dst)); fp = lrt_fnv(fp, &op.src, sizeof(op.src)); fp = lrt_fnv(fp, &op.value, sizeof(op.value)); fp = lrt_fnv(fp, &op.bytes, sizeof(op.bytes)); }
+    }
+    hipError_t e = hipSuccess;
+    for (auto& en : rec->cache)
+        if (en.fp == fp && en.n_ops == rec->ops.size()) { en.stamp = ++rec->clock; rec->hits++; e = hipGraphLaunch(en.exec, stream); rec->ops.clear(); return e; }
+    // unknown sequence: issue it under capture, keep the instantiated graph
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = lrt_rec_issue(rec, stream); rec->ops.clear(); return e; }     // a stream that cannot be captured: eager
+    hipError_t ei = lrt_rec_issue(rec, stream);
+    e = hipStreamEndCapture(stream, &graph);
+    if (ei != hipSuccess || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); e = lrt_rec_issue(rec, stream); rec->ops.clear(); return ei != hipSuccess ? ei : e; }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); (void)hipGetLastError(); e = lrt_rec_issue(rec, stream); rec->ops.clear(); return e; }
+    if (rec->cache.size() >= 16) {
+        size_t v = 0; for (size_t i = 1; i < rec->cache.size(); i++) if (rec->cache[i].stamp < rec->cache[v].stamp) v = i;
+        (void)hipGraphExecDestroy(rec->cache[v].exec); (void)hipGraphDestroy(rec->cache[v].graph); rec->cache.erase(rec->cache.begin() + v);
+    }
+    rec->cache.push_back({fp, rec->ops.size(), graph, exec, ++rec->clock}); rec->captures++;
+    rec->ops.clear();
+    return hipGraphLaunch(exec, stream);
+}
+static void lrt_rec_free(LrtRec* rec) { if (!rec) return; for (auto& en : rec->cache) { (void)hipGraphExecDestroy(en.exec); (void)hipGraphDestroy(en.graph); } rec->cache.clear(); }
+
 #include "lrt_radix.inc"
 
 struct TreeLayout { int L; int cnt[LRT_MAX_LEVELS]; int off[LRT_MAX_LEVELS]; };     // levels 1 .. L of the implicit 8-wide tree: nodes per level, first node of a level
@@ -88,6 +186,8 @@ struct lrt_state {
     int tile_w_log2;
     RsSorter sort_build, sort_bwd; int own_sort;     // radix sorts: 2 (default) = own onesweep (lrt_radix.inc) for builds of >= 131072 primitives and for backward sorts below 1 M keys; 1 = own for both; 0 = rocPRIM
     int n_nodes, n_leaves;
+    LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
+    int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
     int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
@@ -624,7 +724,7 @@ static int tree_layout(int P, int* n_leaves, int* n_levels, int cnt[LRT_MAX_LEVE
 static void finish_tree_now(lrt_state* st, hipStream_t stream)
 {
     if (!st->tree_pending) return;
-    hipLaunchKernelGGL(k_tree_finish, dim3(1), dim3(512), 0, stream, st->nodes, st->nodes_aos, st->tree_lay, st->tree_top);
+    lrt_launch(st->lrec, k_tree_finish, dim3(1), dim3(512), 0, stream, st->nodes, st->nodes_aos, st->tree_lay, st->tree_top);
     st->tree_pending = 0;
 }
 
@@ -642,17 +742,17 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
         TreeLayout lay; memset(&lay, 0, sizeof(lay));
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
-        hipLaunchKernelGGL(k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
+        lrt_launch(st->lrec, k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
                            st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top);
-        if (st->fused_tree == 2 && L >= 4) hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
+        if (st->fused_tree == 2 && L >= 4) lrt_launch(st->lrec, k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
         else if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
         return LRT_OK;
     }
     if (records && Pk > 0)
-        hipLaunchKernelGGL(k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, pack, kept_ptr);
-    hipLaunchKernelGGL(k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
+        lrt_launch(st->lrec, k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, pack, kept_ptr);
+    lrt_launch(st->lrec, k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
     for (int l = 2; l <= L; l++)
-        hipLaunchKernelGGL(k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
+        lrt_launch(st->lrec, k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     return LRT_OK;
 }
 
@@ -732,6 +832,7 @@ lrt_state* lrt_create(int device)
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
+    st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -770,6 +871,7 @@ void lrt_destroy(lrt_state* st)
     (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); rs_free(st->sort_build); rs_free(st->sort_bwd);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
+    lrt_rec_free(st->lrec); delete st->lrec;
     delete st;
 }
 
@@ -777,7 +879,8 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
 {
     if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
     const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
-        {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec}};
+        {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec},
+        {"graph", st->graph_mode}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
     LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: unknown option '%s'", name);
 }
@@ -811,6 +914,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "refine_ties")) { st->refine_ties = value ? 1 : 0; return LRT_OK; }   // 1 (default): hits closer than 2 ulp of t are ordered by their fp64 depth (needs the packed parameter lines of an unculled build); 0: by (t, gidx)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
+    if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
@@ -1170,12 +1274,12 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
                 st->cone_prev = st->cone_host[0];
             }
-            if (n_rays <= 131072) hipLaunchKernelGGL(k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone);
+            if (n_rays <= 131072) lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone);
             else {
                 int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
-                hipLaunchKernelGGL(k_cone_init, dim3(1), dim3(64), 0, stream, cone);
-                hipLaunchKernelGGL(k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
-                hipLaunchKernelGGL(k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
+                lrt_launch(st->lrec, k_cone_init, dim3(1), dim3(64), 0, stream, cone);
+                lrt_launch(st->lrec, k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
+                lrt_launch(st->lrec, k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
             }
         }
         // three bounds sets rotate: this build READS set s (the box of the previous build's centres -- or, on the first build of a state
@@ -1185,10 +1289,10 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         unsigned* barm = st->bounds + 6 * ((st->bounds_sel + 2) % 3);
         st->bounds_sel = (st->bounds_sel + 1) % 3;
         if (!st->bounds_ready || !st->lag_bounds) {
-            const unsigned init6[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-            if (st->bounds_ready) HIPCHK(hipMemcpyAsync(bcur, init6, sizeof(init6), hipMemcpyHostToDevice, stream));   // lag_bounds=0: discard the carried box
+            static const unsigned init6[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};      // static: a recorded copy reads it when the graph runs
+            if (st->bounds_ready) HIPCHK(lrt_memcpy_async(st->lrec, bcur, init6, sizeof(init6), hipMemcpyHostToDevice, stream));   // lag_bounds=0: discard the carried box
             int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;      // few blocks: the 6 atomics per block hit the same words
-            hipLaunchKernelGGL(k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
+            lrt_launch(st->lrec, k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
         }
         st->bounds_ready = 1;
         float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
@@ -1204,27 +1308,28 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             if (gsz < (unsigned long long)P) { keep_cap = (unsigned)(gsz < 64 ? 64 : gsz); spec = true; }
             st->cull_guess = 0;
         }
-        if (spec) HIPCHK(hipMemsetAsync(st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
-        if (cone) hipLaunchKernelGGL(k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
+        if (spec) HIPCHK(lrt_memset_async(st->lrec, st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
+        if (cone) lrt_launch(st->lrec, k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
         else {
             // own onesweep next (decided below by the same rule) and fused_hist: k_morton counts the sort's digit histograms on the way
             int pb_ = 1; while ((1ll << pb_) < (long long)P) pb_++;
             int sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
-            hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && P >= LRT_BUILD_MERGE_LIMIT));
+            hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode)));
             if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
             const int mthreads = hist_fused ? 1024 : TB;
             int mb = (P + mthreads - 1) / mthreads; if (mb > (hist_fused ? 256 : 1024)) mb = hist_fused ? 256 : 1024;
-            hipLaunchKernelGGL(k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
+            lrt_launch(st->lrec, k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
                                hist_fused ? st->sort_build.hist : (unsigned*)nullptr, 63 - sb_, 63);
         }
         if (cone) {
-            HIPCHK(hipMemcpyAsync(st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             st->cone_prev_P = P;
             if (spec) {
-                HIPCHK(hipEventRecord(st->cone_ev, stream));
+                st->cone_ev_due = 1;                             // recorded by the caller once this call's launches have been issued
                 st->cone_pending = 1;
                 Pk = (int)keep_cap;
             } else {                                             // first culled build of this size: one 8-byte read-back
+                HIPCHK(lrt_rec_flush(st->lrec, stream));          // (the recorded launches must run before the host can read their result)
                 HIPCHK(hipStreamSynchronize(stream));
                 Pk = (int)st->cone_host[0];
                 if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
@@ -1238,14 +1343,15 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
             int sort_bits = ((pbits + st->morton_extra + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
-            if (st->own_sort == 1 || (st->own_sort == 2 && Pk >= LRT_BUILD_MERGE_LIMIT)) {      // below the limit rocPRIM's merge sort needs fewer launches
+            if (st->own_sort == 1 || (st->own_sort == 2 && (Pk >= LRT_BUILD_MERGE_LIMIT || st->graph_mode))) {      // below the limit rocPRIM's merge sort needs fewer launches (replayed from a graph the launches cost nothing: own sort)
                 // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
                 int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
                 HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
                 uint64_t* kr = nullptr; uint32_t* vr = nullptr;
-                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused)));
+                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec)));
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
             } else
+            { HIPCHK(lrt_rec_flush(st->lrec, stream)); }                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
             HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
         }
         cone_kept = spec ? cone + 10 : nullptr; pack_used = pack;
@@ -1260,16 +1366,52 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     return LRT_OK;
 }
 
+// Recorded section of an API call (option "graph"): begin before the first launch, end = graph launch (or nothing when the recorder is off).
+// HIP-event timing and the statistics instantiations record events / differ from call to call: those calls stay eager.
+static void rec_begin(lrt_state* st, void* stream_)
+{
+    st->lrec->ops.clear();
+    // the legacy default stream cannot be captured: callers that want graphs run on a stream of their own (torch.cuda.stream(...))
+    st->lrec->on = st->graph_mode && stream_ != nullptr && !st->timing_enabled && !st->stats_enabled && !st->dbg;
+}
+static int rec_end(lrt_state* st, int rc, hipStream_t stream)
+{
+    const hipError_t e = lrt_rec_flush(st->lrec, stream);
+    st->lrec->on = false; st->lrec->ops.clear();
+    if (rc == LRT_OK && e != hipSuccess) LRT_FAIL(LRT_ERR_HIP, "launch recorder: %s", hipGetErrorString(e));
+    return rc;
+}
+
+static int build_call(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod,
+                      int n_rays, const float* ray_o, const float* ray_d, void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "%s: null state", fn);
+    DeviceGuard dg(st->device);
+    rec_begin(st, stream_);
+    st->cone_ev_due = 0;
+    int rc = build_impl(fn, st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
+    rc = rec_end(st, rc, (hipStream_t)stream_);
+    if (st->cone_ev_due) { st->cone_ev_due = 0; if (rc == LRT_OK) HIPCHK(hipEventRecord(st->cone_ev, (hipStream_t)stream_)); }
+    return rc;
+}
+
 int lrt_build(lrt_state* st, int P, const float* means, const float* scales, const float* rots,
               const float* opac, float mod, void* stream_)
 {
-    return build_impl("lrt_build", st, P, means, scales, rots, opac, mod, 0, nullptr, nullptr, stream_);
+    return build_call("lrt_build", st, P, means, scales, rots, opac, mod, 0, nullptr, nullptr, stream_);
 }
 
+static int refit_impl(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod, void* stream_);
 int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod,
               void* stream_)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_refit: null state");
+    DeviceGuard dg(st->device);
+    rec_begin(st, stream_);
+    return rec_end(st, refit_impl(st, P, means, scales, rots, opac, mod, stream_), (hipStream_t)stream_);
+}
+static int refit_impl(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod, void* stream_)
+{
     if (P <= 0 || st->P != P || st->P_built != P || st->order_P != P)
         LRT_FAIL(LRT_ERR_STATE, "lrt_refit: needs a preceding lrt_build of the same %d primitives (not a ray-culled one)", P);
     if (!means || !scales || !rots || !opac) LRT_FAIL(LRT_ERR_ARG, "lrt_refit: null parameter pointer");
@@ -1278,7 +1420,7 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
     float4* pack = st->no_pack ? nullptr : st->pack;
-    if (pack) hipLaunchKernelGGL(k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack);
+    if (pack) lrt_launch(st->lrec, k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack);
     int nl = 0, total = 0;
     int rc = launch_records_and_tree(st, P, means, scales, rots, opac, mod, (const float4*)pack, (const unsigned*)nullptr, true, stream, &total, &nl);
     if (rc) return rc;
@@ -1291,7 +1433,7 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
 int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac,
                        float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_)
 {
-    return build_impl("lrt_build_for_rays", st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
+    return build_call("lrt_build_for_rays", st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
 }
 
 static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t stream)
@@ -1303,17 +1445,17 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     tp.n_tiles = tp.tiles_x * tp.tiles_y;
     tp.rec = st->rec; tp.nodes = st->nodes; tp.tile_counter = st->tile_counter; tp.no_cull = st->no_cull;
     tp.dbg = (!bwd && st->dbg && st->dbg_floats >= (size_t)tp.H * tp.W * 64) ? st->dbg : nullptr;
-    if (tp.dbg) HIPCHK(hipMemsetAsync(tp.dbg, 0, (size_t)tp.H * tp.W * 64 * sizeof(float), stream));
+    if (tp.dbg) HIPCHK(lrt_memset_async(st->lrec, tp.dbg, 0, (size_t)tp.H * tp.W * 64 * sizeof(float), stream));
     tp.stats = st->stats_enabled ? st->stats : nullptr;
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
     if (bwd && st->bwdq_fresh) { tp.tile_counter = st->ctrl + 16; st->bwdq_fresh = 0; }       // zeroed by the forward's prologue, used once
-    else { HIPCHK(hipMemsetAsync(st->tile_counter, 0, 8 * sizeof(unsigned), stream)); if (bwd) HIPCHK(hipMemsetAsync(st->ctrl + 24, 0, 2 * sizeof(unsigned), stream)); }
+    else { HIPCHK(lrt_memset_async(st->lrec, st->tile_counter, 0, 8 * sizeof(unsigned), stream)); if (bwd) HIPCHK(lrt_memset_async(st->lrec, st->ctrl + 24, 0, 2 * sizeof(unsigned), stream)); }
     int blocks = (tp.n_tiles + 3) / 4;
     if (blocks > 256 * 3) blocks = 256 * 3;                       // persistent: <= 3 blocks (12 waves) per CU
     ScopedTimer tm(st, tp.guard == 2 ? -1 : (bwd ? 2 : 1), stream);      // the guarded fallback lies inside the caller's timed region
-    if (bwd) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
-    else     hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
+    if (bwd) lrt_launch(st->lrec, k_trace<true>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
+    else     lrt_launch(st->lrec, k_trace<false>, dim3(blocks), dim3(256), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes);
     HIPCHK(hipGetLastError());
     return LRT_OK;
 }
@@ -1329,9 +1471,23 @@ static int check_common(const char* fn, lrt_state* st, int H, int W, int P, int 
     return LRT_OK;
 }
 
+static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                        const float* shs, const float* bg, int training, float* out9, int32_t* out_i32, float* accum, void* stream_, int* issued);
 int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
                 const float* shs, const float* bg, int training, float* out9, int32_t* out_i32, float* accum,
                 void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null state");
+    DeviceGuard dg(st->device);
+    rec_begin(st, stream_);
+    int issued = 0;
+    int rc = forward_impl(st, H, W, ray_o, ray_d, P, M, deg, shs, bg, training, out9, out_i32, accum, stream_, &issued);
+    rc = rec_end(st, rc, (hipStream_t)stream_);
+    if (rc == LRT_OK && issued) HIPCHK(hipEventRecord(st->hit_ev, (hipStream_t)stream_));      // behind the call's last launch: the status block is complete
+    return rc;
+}
+static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                        const float* shs, const float* bg, int training, float* out9, int32_t* out_i32, float* accum, void* stream_, int* issued)
 {
     (void)training;
     int rc = check_common("lrt_forward", st, H, W, P, M, deg);
@@ -1349,7 +1505,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         const bool fin_tree = st->tree_pending != 0;
-        hipLaunchKernelGGL(k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
+        lrt_launch(st->lrec, k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
                            (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr),
                            fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top);
         st->tree_pending = 0;
@@ -1450,7 +1606,7 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
                     st->tile_w0_n = tp.n_tiles; st->tile_w0_key[0] = -1;
                 }
                 if (memcmp(key, st->tile_w0_key, sizeof(key)) != 0) {
-                    HIPCHK(hipMemsetAsync(st->tile_w0, 0, (size_t)tp.n_tiles * sizeof(float), stream));
+                    HIPCHK(lrt_memset_async(st->lrec, st->tile_w0, 0, (size_t)tp.n_tiles * sizeof(float), stream));
                     memcpy(st->tile_w0_key, key, sizeof(key));
                 }
                 tp.tile_w0 = st->tile_w0;
@@ -1467,19 +1623,19 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
             {   // the STATS instantiations only when counters or the per-tile profile are asked for
                 const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
                 const dim3 g_(blocks), b_(64 * nw);
-#define LRT_CR4(D_, N_, S_) hipLaunchKernelGGL((k_fwd_cr4<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
+#define LRT_CR4(D_, N_, S_) lrt_launch(st->lrec, (k_fwd_cr4<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
                 if (wg4 && nw == 8) { if (dfr) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); } else { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); } }
                 else                { if (dfr) { if (sts) LRT_CR4(true, 4, true); else LRT_CR4(true, 4, false); } else { if (sts) LRT_CR4(false, 4, true); else LRT_CR4(false, 4, false); } }
 #undef LRT_CR4
             }
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
-            hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
+            lrt_launch(st->lrec, k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
             if (dfr) {
                 const int np_ = ((int)HW + 1) / 2;                                                          // two rays per wave
                 const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
                 ScopedTimer tmc(st, 3, stream);                                                             // the colour pass by itself (inside the forward region's timer)
                 // the colour pass is the forward's epilogue as well (status words, hits beyond the record): no k_fwd_fin behind it (option fuse_fin)
-                hipLaunchKernelGGL(k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp, st->fuse_fin ? st->ctrl : (unsigned*)nullptr, st->status_dev);
+                lrt_launch(st->lrec, k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp, st->fuse_fin ? st->ctrl : (unsigned*)nullptr, st->status_dev);
                 fin_done = st->fuse_fin != 0;
             } else { tp.ovf_list = nullptr; }
         }
@@ -1488,12 +1644,12 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
         rc = launch_trace(st, tp, false, stream);
         if (rc) return rc;
         tp.ovf_list = nullptr;
-        if (HW > 0 && P > 0) hipLaunchKernelGGL(k_fwd_near, dim3(64), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
+        if (HW > 0 && P > 0) lrt_launch(st->lrec, k_fwd_near, dim3(64), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
     }
     // epilogue: colours of the hits beyond the record (deferred colour), status words -> host-mapped block, sticky error bits
-    if (!fin_done) hipLaunchKernelGGL(k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
+    if (!fin_done) lrt_launch(st->lrec, k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(st->hit_ev, stream));
+    *issued = 1;                                                     // lrt_forward records hit_ev once the launches have been issued
     st->fwd_pending = 1; st->last_stream = stream; st->bwdq_fresh = 1;
     if (record) {
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
@@ -1503,10 +1659,25 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
     return LRT_OK;
 }
 
+static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                         const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
+                         const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
+                         float* d_opac, float* d_scales, float* d_rots, void* stream_);
 int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
                  const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
                  const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
                  float* d_opac, float* d_scales, float* d_rots, void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null state");
+    DeviceGuard dg(st->device);
+    rec_begin(st, stream_);
+    return rec_end(st, backward_impl(st, H, W, ray_o, ray_d, P, M, deg, means, scales, rots, opac, shs, bg, out9, dL_dout9, d_means, d_shs, d_opac, d_scales, d_rots, stream_),
+                   (hipStream_t)stream_);
+}
+static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                         const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
+                         const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
+                         float* d_opac, float* d_scales, float* d_rots, void* stream_)
 {
     int rc = check_common("lrt_backward", st, H, W, P, M, deg);
     if (rc) return rc;
@@ -1527,7 +1698,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
         for (int i = 0; i < 5;) {
             float* b = seg[i].p; size_t n = seg[i].n; int j = i + 1;
             while (j < 5 && seg[j].p == b + n) { n += seg[j].n; j++; }
-            if (n) HIPCHK(hipMemsetAsync(b, 0, n * sizeof(float), stream));
+            if (n) HIPCHK(lrt_memset_async(st->lrec, b, 0, n * sizeof(float), stream));
             i = j;
         }
         return LRT_OK;
@@ -1608,12 +1779,12 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                     else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                 }
-                hipLaunchKernelGGL(k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
-                hipLaunchKernelGGL(k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
-                if (tp.fast_prep) hipLaunchKernelGGL(k_bwd_prep2, dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
-                else hipLaunchKernelGGL((k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
-                hipLaunchKernelGGL(k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
-                hipLaunchKernelGGL(k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
+                lrt_launch(st->lrec, k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
+                lrt_launch(st->lrec, k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
+                if (tp.fast_prep) lrt_launch(st->lrec, k_bwd_prep2, dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
+                else lrt_launch(st->lrec, (k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
+                lrt_launch(st->lrec, k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
+                lrt_launch(st->lrec, k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise; k_bk_sort left rows of zeros)
                     tp.guard = 2;
                     HIPCHK(hipGetLastError());
@@ -1624,11 +1795,12 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
             }
             if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
-                hipLaunchKernelGGL(k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
+                lrt_launch(st->lrec, k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
             } else if (tp.n_tiles > 0) {
                 // (1) per-ray replay -> two scalars per hit, (2) radix sort of the (g, id) keys, (3) segmented reduction
                 ScopedTimer tm(st, 2, stream);
                 tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk; tp.hit_wa = st->hit_wa;
+                HIPCHK(lrt_rec_flush(st->lrec, stream));                  // rocPRIM launches by itself: the rest of this call is eager
                 { size_t sb = st->scan_tmp_bytes;
                   HIPCHK(rocprim::exclusive_scan(st->scan_tmp, sb, (unsigned*)st->hit_n, st->hit_off, 0u, (size_t)H * W, rocprim::plus<unsigned>(), stream)); }
                 int id_bits = 1; while ((1ull << id_bits) < (unsigned long long)H * W * (unsigned long long)tp.hit_cap) id_bits++;
@@ -1638,8 +1810,8 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     const int hw = H * W;
                     const int blocks = hw < 256 * 32 ? hw : 256 * 32;               // persistent one-wave workgroups, grid-stride over rays
                     tp.fast_prep = st->fast_valid;
-                    if (tp.fast_prep) { hipLaunchKernelGGL((k_bwd_prep<true, false>), dim3(blocks), dim3(64), 0, stream, tp); st->fast_valid = 0; }   // hit_pk's colours are now overwritten: a second backward recomputes them
-                    else hipLaunchKernelGGL((k_bwd_prep<false, false>), dim3(blocks), dim3(64), 0, stream, tp);
+                    if (tp.fast_prep) { lrt_launch(st->lrec, (k_bwd_prep<true, false>), dim3(blocks), dim3(64), 0, stream, tp); st->fast_valid = 0; }   // hit_pk's colours are now overwritten: a second backward recomputes them
+                    else lrt_launch(st->lrec, (k_bwd_prep<false, false>), dim3(blocks), dim3(64), 0, stream, tp);
                 }
                 if (n_hits > 0) {
                     int gbits = 1; while ((1ll << gbits) < (long long)P) gbits++;
@@ -1649,7 +1821,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     if (st->own_sort == 1 || (st->own_sort == 2 && n_hits < (1u << 20))) {      // large sorts: rocPRIM's pass is faster (38 vs 47 us at 4 M keys), small ones are launch bound
                         HIPCHK(rs_reserve(st->sort_bwd, st->key_cap, 8, stream));
                         unsigned long long* kr = nullptr;
-                        HIPCHK((rs_sort<unsigned long long, false, 8>(st->sort_bwd, st->hit_keys, st->hit_keys_sorted, nullptr, nullptr, n_hits, id_bits, id_bits + gbits, stream, &kr, nullptr)));
+                        HIPCHK((rs_sort<unsigned long long, false, 8>(st->sort_bwd, st->hit_keys, st->hit_keys_sorted, nullptr, nullptr, n_hits, id_bits, id_bits + gbits, stream, &kr, nullptr, false, st->lrec)));
                         tp.sorted_keys = kr;
                         if (kr != st->hit_keys_sorted) { unsigned long long* t_ = st->hit_keys; st->hit_keys = st->hit_keys_sorted; st->hit_keys_sorted = t_; }
                     } else {
@@ -1657,7 +1829,7 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                     tp.sorted_keys = st->hit_keys_sorted;
                     }
                     tp.n_hits = n_hits;
-                    hipLaunchKernelGGL(k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
+                    lrt_launch(st->lrec, k_bwd_reduce3, dim3((n_hits + 255) / 256), dim3(256), 0, stream, tp);
                 }
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise)
                     tp.guard = 2;

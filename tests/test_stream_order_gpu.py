@@ -126,3 +126,49 @@ def test_overflow_in_a_run_ahead_loop_is_still_reported():
     _step(tr, t, ro, rd, dL); torch.cuda.synchronize()    # reported once; the state recovers
     tr.check(DEV)
     del keep
+
+
+def test_hip_graph_replay_gives_the_eager_results_bit_for_bit():
+    """Option "graph": the launch sequence of every API call is recorded, fingerprinted and replayed from an instantiated HIP graph
+    (one graph launch per call instead of one launch per kernel; the legacy default stream cannot be captured, so the step runs on a side
+    stream).  Over steps with changing parameters the results must equal the eager path's bit for bit in the forward (hits are ordered by
+    (t, gidx)) and to float-atomic noise in the gradients, the graphs must actually be replayed, and a capacity change (a scene with
+    another P) must simply be another graph."""
+    from lidar_rt_amd import scenes
+    from lidar_rt_amd.diff_lidar_tracer import Tracer
+    from tests.hip_util import settings, DEFAULT_OPTS
+    sc, o, d = scenes.s10k()
+    dL = scenes.upstream_grad(*o.shape[:2])
+    ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")
+    g = torch.as_tensor(dL, device="cuda:0")
+    side = torch.cuda.Stream()
+    res = {}
+    for graph in (0, 1):
+        tr = Tracer()
+        for k, v in {**DEFAULT_OPTS, "graph": graph}.items():
+            tr.optix_context.set_option(k, v)
+        outs = []
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for step in range(12):
+                cur = dict(sc)
+                cur["means"] = (sc["means"] + 0.002 * (step % 5)).astype(np.float32)
+                if step == 9:                                              # another P: new capacities, new graphs
+                    cur = {k: np.ascontiguousarray(v[:-100]) for k, v in cur.items()}
+                t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in cur.items()}
+                tr.build_from_gaussians(t["means"], t["scales"], t["rotations"], t["opacities"])
+                out, acc = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"],
+                              scales=t["scales"], rotations=t["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
+                out.backward(g)
+                outs.append((out.detach().clone(), acc.detach().clone(), {k: t[k].grad.clone() for k in ("means", "scales", "rotations", "opacities", "shs")}))
+        side.synchronize()
+        res[graph] = outs
+        if graph:
+            hits, caps = tr.optix_context.get_option("graph_hits", "cuda:0"), tr.optix_context.get_option("graph_captures", "cuda:0")
+            assert hits >= 12 and 3 <= caps <= 30, (hits, caps)             # most calls were replays; a handful of distinct sequences were instantiated
+        tr.optix_context.set_option("graph", 0)
+    for (oa, aa, ga), (ob, ab, gb) in zip(res[0], res[1]):
+        assert torch.equal(oa, ob)
+        assert float((aa - ab).abs().max()) <= 1e-6 * float(aa.abs().max())
+        for k in ga:
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(ga[k].abs().max()), k
