@@ -1350,9 +1350,10 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 uint64_t* kr = nullptr; uint32_t* vr = nullptr;
                 HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec)));
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
-            } else
-            { HIPCHK(lrt_rec_flush(st->lrec, stream)); }                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
-            HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
+            } else {
+                HIPCHK(lrt_rec_flush(st->lrec, stream));                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
+                HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
+            }
         }
         cone_kept = spec ? cone + 10 : nullptr; pack_used = pack;
     }

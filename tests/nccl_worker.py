@@ -39,7 +39,26 @@ def main():
         for k in ("means", "shs", "accum"):
             rel[f"{ex}.{k}"] = float((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
     torch.cuda.synchronize()
-    print(json.dumps({"backend": dist.get_backend(), "exchanges": ["owner", "dense", "sparse"], "rel_err": rel}), flush=True)
+    # ---- the sharded step (forward + slab all_gather + backward + device-side gathering exchange) enqueued behind a busy GPU: it must
+    # return to the host without waiting for the device (no count read-back inside the exchange since round 4)
+    import time
+    tr = ShardedTracer(exchange="sparse"); tr.force_collectives = True
+    for _ in range(4):
+        tr.forward(ro, rd, *args); tr.backward(*args, g_up)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(1_000_000); torch.cuda.synchronize()
+    t0 = time.perf_counter(); torch.cuda._sleep(20_000_000); torch.cuda.synchronize()
+    rate = 20_000_000 / max(time.perf_counter() - t0, 1e-6)
+    torch.cuda._sleep(int(0.4 * rate))
+    marker = torch.cuda.Event(); marker.record()
+    t0 = time.perf_counter()
+    tr.forward(ro, rd, *args); tr.backward(*args, g_up)
+    host_s = time.perf_counter() - t0
+    still_busy = not marker.query()
+    torch.cuda.synchronize()
+    tr.check()
+    print(json.dumps({"backend": dist.get_backend(), "exchanges": ["owner", "dense", "sparse"], "rel_err": rel,
+                      "sharded_step_host_s": host_s, "gpu_still_busy_after_enqueue": bool(still_busy)}), flush=True)
     dist.destroy_process_group()
 
 

@@ -65,6 +65,8 @@ def test_rccl_preflight_world_of_one():
     res = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert res["backend"] == "nccl" and set(res["exchanges"]) == {"owner", "dense", "sparse"}
     assert all(v < 1e-6 for v in res["rel_err"].values()), res
+    # the whole sharded step (incl. the device-side gathering exchange) was enqueued behind 0.4 s of GPU work without the host waiting
+    assert res["gpu_still_busy_after_enqueue"] and res["sharded_step_host_s"] < 0.1, res
 
 
 def test_an_overflow_on_one_rank_is_raised_by_all_ranks():

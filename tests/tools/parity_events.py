@@ -110,11 +110,15 @@ def classify(seq, r):
     return "other"
 
 
+RAY_CLASS = {}
+
+
 def table(name, seq_of, out_x):
     scale = lambda c: np.maximum(np.abs(ref_out[:, c]), 1e-3 * np.abs(ref_out[:, c]).max())
     bad = {c: np.abs(out_x[:, c] - ref_out[:, c]) / scale(c) > 1e-4 for c in (0, 2, 3)}
     any_bad = bad[0] | bad[2] | bad[3]
     rows = {}
+    per_ray = np.empty(HW, object)
     # candidates for a difference: every ray beyond tolerance + a sample of the others is not enough -- sequences can differ without a
     # visible error, so all rays are compared (vectorised pre-filter on length and content)
     for r in range(HW):
@@ -125,9 +129,11 @@ def table(name, seq_of, out_x):
             kind = "same sequence, within 1e-4"
         else:
             kind = classify(list(seq), r)
+        per_ray[r] = kind
         e = rows.setdefault(kind, {"rays": 0, "intensity": 0, "raydrop": 0, "depth": 0})
         e["rays"] += 1; e["intensity"] += int(bad[0][r]); e["raydrop"] += int(bad[2][r]); e["depth"] += int(bad[3][r])
     tot = {k: sum(v[k] for v in rows.values()) for k in ("rays", "intensity", "raydrop", "depth")}
+    RAY_CLASS[name] = per_ray
     return {"implementation": name, "classes": rows, "total": tot, "frac_beyond_1e-4": {k: tot[k] / HW for k in ("intensity", "raydrop", "depth")}}
 
 
@@ -147,3 +153,61 @@ a, b = res["hip"]["total"], res["f32_oracle"]["total"]
 lines.append(f"| **total** | {a['rays']} | {a['intensity']} / {a['raydrop']} / {a['depth']} | {b['rays']} | {b['intensity']} / {b['raydrop']} / {b['depth']} |")
 open(os.path.join(REPO, "gpurun_out", f"{tag}_parity_events_{wl}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Gradients: which ray EVENT moved a Gaussian's gradient beyond 1e-3?  For every Gaussian whose d_opacity (and
+# d_means) of an fp32 implementation leaves the fp64 oracle's by more than 1e-3 relative (floor 1e-3 of the tensor's maximum), the rays
+# that composite it (fp64 trace) are looked up in the per-ray event classes above; the Gaussian is filed under the most consequential
+# event among its rays (restart epsilon > T-stop edge > 1/255 edge > order swap > other > arithmetic only).
+if os.environ.get("PARITY_GRADS", "1") == "1":
+    dL = scenes.upstream_grad(H, W)
+    grads = {}
+    for prec in ("f32", "f64"):
+        orc = oracle.Oracle(sc["means"], sc["scales"], sc["rotations"], sc["opacities"], prec)
+        fw_ = orc.forward(o, d, sc["shs"], 3, bg)
+        grads[prec] = orc.backward(o, d, sc["shs"], 3, bg, fw_["out"], dL)
+        del orc
+    gh = be.backward(torch.as_tensor(o, device=dev), torch.as_tensor(d, device=dev), t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3,
+                     torch.as_tensor(bg, device=dev), out, torch.as_tensor(dL, device=dev))
+    torch.cuda.synchronize()
+    grads["hip"] = {k: v.cpu().numpy() for k, v in gh.items()}
+    # Gaussian -> rays that composite it (fp64 trace)
+    comp_mask = (f64_ & 1) > 0
+    comp_mask &= np.arange(CAP)[None, :] < np.minimum(n64, CAP)[:, None]
+    rr_, kk_ = np.nonzero(comp_mask)
+    gg_ = g64[rr_, kk_]
+    order_ = np.argsort(gg_, kind="stable"); gg_s, rr_s = gg_[order_], rr_[order_]
+    P = sc["means"].shape[0]
+    start_ = np.searchsorted(gg_s, np.arange(P + 1))
+    SEV = ["restart epsilon", "T-stop edge", "1/255 edge", "order swap", "other", "same sequence (0.99 clamp edge)", "same sequence"]
+
+    def grad_table(impl, ray_cls):
+        sev_code = np.full(HW, len(SEV), np.int32)
+        for i_, nm in enumerate(SEV):
+            sev_code[np.asarray([c == nm for c in ray_cls])] = i_
+        out_rows = {}
+        for field in ("opacities", "means", "shs"):
+            a_ = np.asarray(grads[impl][field], np.float64).reshape(P, -1); b_ = np.asarray(grads["f64"][field], np.float64).reshape(P, -1)
+            scale_ = np.maximum(np.abs(b_), 1e-3 * np.abs(b_).max())
+            badg = np.nonzero((np.abs(a_ - b_) / scale_ > 1e-3).any(1))[0]
+            cnt = {nm: 0 for nm in SEV + ["arithmetic only (all its rays: same sequence, within 1e-4)"]}
+            for g_ in badg:
+                rays_ = rr_s[start_[g_]:start_[g_ + 1]]
+                code = int(sev_code[rays_].min()) if len(rays_) else len(SEV)
+                cnt[SEV[code] if code < len(SEV) else "arithmetic only (all its rays: same sequence, within 1e-4)"] += 1
+            out_rows[field] = {"gaussians_beyond_1e-3": int(len(badg)), "touched_gaussians": int((start_[1:] > start_[:-1]).sum()), "by_event": cnt}
+        return out_rows
+
+    gres = {"workload": wl, "gaussians": int(P), "hip": grad_table("hip", RAY_CLASS["HIP (k_fwd_cr4)"]), "f32_oracle": grad_table("f32", RAY_CLASS["fp32 oracle"])}
+    json.dump(gres, open(os.path.join(REPO, "gpurun_out", f"{tag}_parity_events_grads_{wl}.json"), "w"), indent=1)
+    gl = [f"# Gradient parity events on {wl}: Gaussians whose gradient leaves the fp64 oracle's by more than 1e-3 (relative, floor 1e-3 of the tensor maximum), "
+          "filed under the most consequential EVENT among the rays that composite them (events = first difference of a ray's composited sequence from the fp64 oracle's)\n"]
+    for field in ("opacities", "means", "shs"):
+        hh, ff = gres["hip"][field], gres["f32_oracle"][field]
+        gl.append(f"## d_{field}: HIP {hh['gaussians_beyond_1e-3']} of {hh['touched_gaussians']} touched Gaussians beyond 1e-3; fp32 oracle {ff['gaussians_beyond_1e-3']}\n")
+        gl.append("| event among the Gaussian's rays | HIP Gaussians | fp32-oracle Gaussians |"); gl.append("|---|---:|---:|")
+        for nm in SEV + ["arithmetic only (all its rays: same sequence, within 1e-4)"]:
+            gl.append(f"| {nm} | {hh['by_event'][nm]} | {ff['by_event'][nm]} |")
+        gl.append("")
+    open(os.path.join(REPO, "gpurun_out", f"{tag}_parity_events_grads_{wl}.md"), "w").write("\n".join(gl) + "\n")
+    print("\n".join(gl))
