@@ -190,6 +190,7 @@ struct lrt_state {
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
+    int key32;           // 1 (default): 32-bit sort keys (Morton code >> 31) for builds that use the own radix sort
     int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
     int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
@@ -833,7 +834,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -916,6 +917,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
+    if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
@@ -1301,7 +1303,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         // count + 4096; the unused tail holds sentinel keys (sorted last, turned into padding by k_make_records) and the actual count
         // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
         unsigned keep_cap = (unsigned)P;
-        bool spec = false, hist_fused = false;
+        bool spec = false, hist_fused = false, key32 = false;
         if (cone && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
             unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess
                                                         : (st->cone_prev + st->cone_prev / 4 + 4096ull);
@@ -1316,10 +1318,11 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             int sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
             hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode)));
             if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
+            key32 = st->key32 && (st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode))) && LRT_SORT_LO_BIT == 31;
             const int mthreads = hist_fused ? 1024 : TB;
             int mb = (P + mthreads - 1) / mthreads; if (mb > (hist_fused ? 256 : 1024)) mb = hist_fused ? 256 : 1024;
             lrt_launch(st->lrec, k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
-                               hist_fused ? st->sort_build.hist : (unsigned*)nullptr, 63 - sb_, 63);
+                               hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb_ : 63 - sb_, key32 ? 32 : 63, key32 ? 1 : 0);
         }
         if (cone) {
             HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1348,6 +1351,11 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
                 HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
                 uint64_t* kr = nullptr; uint32_t* vr = nullptr;
+                if (key32) {                                               // k_morton wrote 32-bit keys (code >> 31) into the key buffer
+                    uint32_t* kr32 = nullptr;
+                    HIPCHK((rs_sort<uint32_t, true, 8>(st->sort_build, reinterpret_cast<uint32_t*>(st->keys_a), reinterpret_cast<uint32_t*>(st->keys_b), st->vals_a, st->vals_b,
+                                                       (unsigned)Pk, 32 - sb, 32, stream, &kr32, &vr, hist_fused, st->lrec)));
+                } else
                 HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec)));
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
             } else {
