@@ -190,8 +190,6 @@ struct lrt_state {
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
-    unsigned char* touched; long long build_serial, hit_build_serial;
-    int* rank_of; int bk_rank, rank_valid;   // position of every Gaussian in the LBVH's sorted order (written by k_make_tree of an unculled build): the bucketed backward keys its buckets by it (option bk_rank)
     int key32;           // 1 (default): 32-bit sort keys (Morton code >> 31) for builds that use the own radix sort
     int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
     int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
@@ -248,7 +246,6 @@ struct TraceParams {
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     float2* hit_wa;        // deferred-colour forward: per recorded hit (composite weight, unclamped op*G)
-    const int* rank_of; const unsigned* order_r; unsigned char* touched;   // bucketed backward keyed by the LBVH order (option bk_rank): position of a Gaussian, index at a position, per-Gaussian hit marks
     int prezeroed;         // backward: the gradient tensors are all-zero on entry (option grads_prezeroed): no zero rows are stored
     int fast_prep;         // backward: hit_wa / hit_pk hold the forward's alpha and colour of every recorded hit
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
@@ -747,8 +744,7 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
         lrt_launch(st->lrec, k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
-                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top,
-                           (st->bk_rank && !kept_ptr) ? st->rank_of : (int*)nullptr);
+                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top);
         if (st->fused_tree == 2 && L >= 4) lrt_launch(st->lrec, k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
         else if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
         return LRT_OK;
@@ -767,17 +763,14 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top, st->rank_of, st->touched};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top};
     for (void* q : olds) (void)hipFree(q);
-    st->rank_of = nullptr; st->touched = nullptr; st->rank_valid = 0;
     st->nodes_aos = nullptr; st->pack = nullptr; st->tree_top = nullptr; st->tree_top_words = 0; st->tree_pending = 0;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
     HIPCHK(hipMalloc(&st->rec, (cap + LRT_LEAF) * LRT_REC_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc(&st->aabb, cap * 6 * sizeof(float)));
     HIPCHK(hipMalloc(&st->pack, cap * 4 * sizeof(float4)));
-    HIPCHK(hipMalloc(&st->rank_of, cap * sizeof(int)));
-    HIPCHK(hipMalloc(&st->touched, cap)); HIPCHK(hipMemset(st->touched, 0, cap));
     HIPCHK(hipMalloc(&st->keys_a, cap * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&st->keys_b, cap * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&st->vals_a, cap * sizeof(uint32_t)));
@@ -841,8 +834,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4; st->key32 = 1;
-    { const char* e_ = getenv("LRT_BK_RANK"); if (e_) st->bk_rank = atoi(e_) ? 1 : 0; }      // developer / test switch for the default          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -871,7 +863,7 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone, st->tree_top, st->rank_of, st->touched};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone, st->tree_top};
     if (st->cone_host) { (void)hipHostFree(st->cone_host); (void)hipEventDestroy(st->cone_ev); }
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -925,7 +917,6 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
-    if (!strcmp(name, "bk_rank")) { st->bk_rank = value ? 1 : 0; st->hits_valid = 0; return LRT_OK; }   // 1: the bucketed backward's buckets hold Gaussians adjacent in the LBVH order, not in index order
     if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
@@ -1379,8 +1370,6 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
-    st->build_serial++;
-    st->rank_valid = (st->bk_rank && st->fused_tree && n_rays == 0 && P > 0) ? 1 : 0;     // k_make_tree wrote rank_of for every Gaussian
     st->pack_valid = (P > 0 && !st->no_pack) ? 1 : 0;     // k_morton / k_morton_cull wrote the packed lines of every primitive that can be hit
     st->order_P = (n_rays == 0 && P > 0) ? P : -1;
     return LRT_OK;
@@ -1543,7 +1532,6 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         st->near_cap = HW;
     }
     tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
-    tp.rank_of = (st->bk_rank && st->rank_valid && st->bwd_mode == 3) ? st->rank_of : nullptr;
     const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     bool fin_done = false;
@@ -1674,7 +1662,6 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
     st->fwd_pending = 1; st->last_stream = stream; st->bwdq_fresh = 1;
     if (record) {
         st->hits_valid = (training && st->replay_enabled) ? 1 : 0; st->hit_H = H; st->hit_W = W;
-        st->hit_build_serial = tp.rank_of ? st->build_serial : -1;      // the colour record carries positions of THIS build's order
         st->fast_valid = (st->hits_valid && defer) ? 1 : 0;          // alpha and colour of every recorded hit are on the device
         if (st->hits_valid) { st->est_pending = 1; st->pend_hw = HW; }
     }
@@ -1793,11 +1780,6 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 tp.brec = st->brec; tp.brec2 = st->brec2; tp.bkg = st->bk_g; tp.rec_cap = st->key_cap; tp.bk_M = st->bk_M;
                 tp.bk_aux = st->bk_small; tp.bk_base = st->bk_small + (size_t)BK_RB * bk_nb;
                 tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg;
-                // rank mode: buckets of Gaussians adjacent in the LBVH order (their rays are neighbours: the reduction's 64-byte ray gathers
-                // become coherent); needs the positions of the build the forward traced (a rebuild in between: index keys)
-                if (st->bk_rank && st->rank_valid && st->P_built == P && (!st->fast_valid || st->hit_build_serial == st->build_serial)) {
-                    tp.rank_of = st->rank_of; tp.order_r = st->vals_b; tp.touched = st->touched;
-                }
                 if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
                 const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
                 tp.fast_prep = st->fast_valid;
