@@ -442,6 +442,7 @@ def main():
                                + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (device-side: one pack launch, one all_gather, one apply launch; capacity overflows are flagged on the device and raised by the next step)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND,
+                       "slab_edges": (list(tr._edges) if getattr(tr, "_edges", None) is not None else ([column_slab(W, r, world)[0] for r in range(world)] + [W] if world > 1 else None)),
                        "hip_graph": ({"replays": st.get_option("graph_hits", dev), "instantiated": st.get_option("graph_captures", dev)} if args.graph else None)},
             "roofline": roof,
             # per-phase GPU time per step on rank 0 (HIP events): LBVH build / forward trace / backward; N > 1: + slab all_gather and

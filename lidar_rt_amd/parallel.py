@@ -166,6 +166,14 @@ class ShardedTracer:
         self._flat_dirty = True        # the flat buffer may hold anything: clear it whole before the next backward
         self._xchg_par = 0
         self._cap_hist = []            # list lengths of the last exchanges (capacity = 1.5 x their maximum + 4096)
+        # load balance: azimuth sectors of equal width are not sectors of equal work (waymo4m shape, 4 ranks: 1.7 against 2.4 ms per rank).  Every
+        # rank times its own build + forward + backward (two events), the times travel in the header of the slab all_gather, and every
+        # `balance_every` steps all ranks move the slab edges towards equal time -- the same arithmetic on the same gathered numbers
+        self.balance = isinstance(self.backend, HipBackend) and os.environ.get("LRT_BALANCE", "1") == "1"
+        self.balance_every = int(os.environ.get("LRT_BALANCE_EVERY", "8"))
+        self._edges, self._edges_key = None, None      # column edges [0, .., W] of the current split (None: equal widths)
+        self._step_no = 0
+        self._t_events, self._t_last_ms, self._times = None, 0.0, None
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True):
@@ -214,6 +222,9 @@ class ShardedTracer:
             if ev is not None:
                 ev.synchronize()
             vals = host.reshape(-1).tolist()
+            if what == "times":                                      # every rank's compute time of an earlier step (ms), identical on all ranks
+                self._times = [float(v) for v in vals]
+                continue
             if what == "exchange":                                   # [overflow flag, list length of every rank]: identical on all ranks
                 self._cap_hist = (self._cap_hist + [max(int(v) for v in vals[1:])])[-8:]
                 vals = vals[:1]
@@ -264,13 +275,50 @@ class ShardedTracer:
             return False
         return name in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
 
+    # ---- slab edges ----------------------------------------------------------------------------------------------------------------
+    def slab_of(self, W: int, rank: int) -> Tuple[int, int]:
+        if self._edges is not None and self._edges_key == (W, self.world):
+            return self._edges[rank], self._edges[rank + 1]
+        return column_slab(W, rank, self.world)
+
+    def _rebalance(self, W: int):
+        """Move the slab edges towards equal compute time per rank.  Rank r processed its `w_r` columns in `t_r` ms, i.e. at w_r / t_r columns
+        per ms; widths proportional to those rates would equalise the times if the cost per column were uniform inside a slab, so the step
+        is damped (half way) and widths stay multiples of the 8-column tile.  Deterministic: identical inputs on every rank."""
+        t = self._times
+        if not t or len(t) != self.world or min(t) <= 0.0:
+            return
+        if self._edges is None or self._edges_key != (W, self.world):
+            self._edges = [column_slab(W, r, self.world)[0] for r in range(self.world)] + [W]; self._edges_key = (W, self.world)
+        w = [self._edges[r + 1] - self._edges[r] for r in range(self.world)]
+        rate = [w[r] / t[r] for r in range(self.world)]
+        tot = sum(rate)
+        want = [0.5 * w[r] + 0.5 * W * rate[r] / tot for r in range(self.world)]
+        edges, acc = [0], 0.0
+        for r in range(self.world - 1):
+            acc += want[r]
+            e = int(round(acc / 8.0)) * 8
+            e = max(e, edges[-1] + 8); e = min(e, W - 8 * (self.world - 1 - r))
+            edges.append(e)
+        edges.append(W)
+        if all(edges[i + 1] > edges[i] for i in range(self.world)):
+            self._edges = edges
+
     # ---- forward ----------------------------------------------------------------------------------------------------------------
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
         H, W = ray_o.shape[:2]
         self._dev = means.device
         if self.world > 1 or self.force_collectives:
             self.check(wait=True)                              # statuses and counts of the previous step: long there; all ranks agree
-        a, b = column_slab(W, self.rank, self.world)
+        timed = self.balance and self.world > 1 and means.is_cuda and W >= 16 * self.world
+        if timed:
+            if self._t_events is not None and self._t_events[1].query():
+                self._t_last_ms = float(self._t_events[0].elapsed_time(self._t_events[1]))
+            self._step_no += 1
+            if self._step_no % self.balance_every == 0:
+                self._rebalance(W)
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
+        a, b = self.slab_of(W, self.rank)
         self._slab = (a, b)
         self._ro = ray_o[:, a:b].contiguous(); self._rd = ray_d[:, a:b].contiguous()
         self._rays_full = (ray_o, ray_d)
@@ -290,20 +338,25 @@ class ShardedTracer:
         if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
         # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
+        self._timed_ev0 = ev0 if timed else None
         with self._Region(self, "slab_all_gather", out_loc.device):
-            wmax = max(column_slab(W, r, self.world)[1] - column_slab(W, r, self.world)[0] for r in range(self.world))
+            wmax = max(self.slab_of(W, r)[1] - self.slab_of(W, r)[0] for r in range(self.world))
             msg = torch.zeros(2 + H * wmax * 9, dtype=out_loc.dtype, device=out_loc.device)
+            if timed:
+                msg[1] = self._t_last_ms                     # word 1: this rank's compute time (ms) of its last timed step
             msg[2:].view(H, wmax, 9)[:, :b - a] = out_loc
             if hasattr(self.backend, "status_to") and out_loc.is_cuda:
                 self.backend.status_to(msg)                  # word 0: this rank's forward / build status bits
             parts = self._all_gather_rows(msg)               # one flat receive buffer with RCCL
             cols = []
             for r in range(self.world):
-                ra, rb = column_slab(W, r, self.world)
+                ra, rb = self.slab_of(W, r)
                 cols.append(parts[r][2:].view(H, wmax, 9)[:, :rb - ra])
             full = torch.cat(cols, dim=1)
             hdr = torch.stack([p[:2] for p in parts])        # (N, 2), identical on every rank
             self._remember("forward", hdr[:, 0])
+            if timed:
+                self._remember("times", hdr[:, 1])
         return full, accum_loc                          # accum is completed by backward()'s exchange
 
     # ---- backward ---------------------------------------------------------------------------------------------------------------
@@ -344,6 +397,9 @@ class ShardedTracer:
             g = self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg, out_loc_, dL, mod)
             for k in direct:
                 direct[k].copy_(g[k].view_as(direct[k]))
+        if getattr(self, "_timed_ev0", None) is not None:          # this rank's own compute of the step ends here (the exchange is not the rank's work)
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record()
+            self._t_events = (self._timed_ev0, ev1); self._timed_ev0 = None
         self.last_exchange = None
         if not exchanging:
             if pz:                                             # leave this step's own list behind for the next step's clearing
@@ -405,7 +461,7 @@ class ShardedTracer:
         origin = ray_o.reshape(-1, 3).mean(0)
         axes = []
         for r in range(self.world):
-            ra, rb = column_slab(W, r, self.world)
+            ra, rb = self.slab_of(W, r)
             d = ray_d[:, ra:rb].reshape(-1, 3)
             m = (d / d.norm(dim=1, keepdim=True).clamp_min(1e-30)).mean(0)
             axes.append(m / m.norm().clamp_min(1e-30))

@@ -32,6 +32,20 @@ def test_two_ranks_on_one_gpu_match_single_rank():
         assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (k, a["checksums"], b["checksums"])
 
 
+def test_rebalanced_slabs_give_the_single_rank_results():
+    """The slab edges move towards equal compute time per rank (every LRT_BALANCE_EVERY steps, from the times every rank sends along with
+    its slab): whatever split the ranks agree on, image and gradients equal the single-rank run's."""
+    a = _bench(1)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", LRT_SINGLE_DEVICE="1", LRT_DIST_BACKEND="gloo", LRT_BALANCE_EVERY="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", "29615",
+           os.path.join(REPO, "bench.py"), "--gpus", "3", "--steps", "9", "--warmup", "2", "--workload", "s10k", "--no-cpu-baseline", "--check-sum", "--min-seconds", "0"]
+    out = subprocess.run(cmd, check=True, env=env, cwd=REPO, timeout=600, capture_output=True, text=True).stdout
+    b = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert b["config"].get("slab_edges") is not None                  # the split that was in use at the end (may or may not have moved)
+    for k in ("out", "d_means", "d_shs", "accum"):
+        assert abs(a["checksums"][k] - b["checksums"][k]) <= 2e-5 * max(abs(a["checksums"][k]), 1e-12), (k, a["checksums"], b["checksums"])
+
+
 def test_three_ranks_with_ray_culled_builds_match_single_rank():
     """The default from eight ranks on (every rank builds the LBVH for its own slab's rays, sized speculatively from the previous frame)
     end to end through ShardedTracer, forced on at three ranks."""

@@ -9,7 +9,7 @@ from lidar_rt_amd import scenes
 from lidar_rt_amd.parallel import HipBackend, column_slab, GradLayout
 
 dev = torch.device("cuda:0")
-sc, ro, rd = scenes.s1m()
+sc, ro, rd = scenes.waymo_dynamic_4m() if os.environ.get("WORKLOAD", "s1m") == "waymo4m" else scenes.s1m()      # WORKLOAD=waymo4m: BASELINE configs[4]'s shape
 t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
 H, W = ro.shape[:2]
 dL = torch.as_tensor(scenes.upstream_grad(H, W), device=dev)
@@ -19,7 +19,7 @@ tr = ShardedTracer()                              # one rank: what a rank of an 
 be = tr.backend
 for kv in os.environ.get("LRT_OPTS", "").split(","):
     if kv: be.state.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-lay = GradLayout(1000000, 16, dev)
+lay = GradLayout(int(sc["means"].shape[0]), 16, dev)
 grads = {k: lay.views[k] for k in ("means", "scales", "rotations", "opacities", "shs")}
 NS = tuple(int(x) for x in os.environ.get("SLAB_N", "1,2,4,8").split(","))
 for N in NS:
