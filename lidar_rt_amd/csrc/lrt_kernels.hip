@@ -797,7 +797,8 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
 }
 
 struct ScopedTimer {
-    lrt_state* st; hipStream_t stream; lrt_state::TimerSlot* slot = nullptr;
+    // the slot is kept as an INDEX: timers nest (the colour pass inside the forward region) and the inner one may grow the vector
+    lrt_state* st; hipStream_t stream; long idx = -1;
     ScopedTimer(lrt_state* s, int kind, hipStream_t str) : st(s), stream(str)
     {
         if (!st->timing_enabled || kind < 0) return;
@@ -806,11 +807,11 @@ struct ScopedTimer {
             if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
             st->timers->push_back(t);
         }
-        slot = &(*st->timers)[st->timers_used++];
-        slot->kind = kind;
-        (void)hipEventRecord(slot->a, stream);
+        idx = (long)st->timers_used++;
+        (*st->timers)[idx].kind = kind;
+        (void)hipEventRecord((*st->timers)[idx].a, stream);
     }
-    ~ScopedTimer() { if (slot) (void)hipEventRecord(slot->b, stream); }
+    ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord((*st->timers)[idx].b, stream); }
 };
 
 extern "C" {
