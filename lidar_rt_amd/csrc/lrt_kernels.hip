@@ -1,12 +1,13 @@
 // lrt_kernels.hip -- MI355X (gfx950 / CDNA4) differentiable LiDAR Gaussian tracer: state, C ABI (include/lrt.h) and launch logic.
 //
 // What this translation unit replaces in the reference (zju3dv/LiDAR-RT, DLT = submodules/diff-lidar-tracer):
-//   lib/utils/primitive_utils.py:182-224   build2DRectangle      -> k_make_records (quads are implicit)
-//   DLT/trace_surfels.cpp:46-148           OptiX GAS build        -> software LBVH: k_morton, own onesweep radix sort (lrt_radix.inc),
-//                                                                   k_make_records, implicit 8-wide tree built level by level (lrt_build.inc)
-//   DLT/optix_tracer/forward.cu:146-356    raygen + anyhit (fwd)  -> k_fwd_cr4 + k_fwd_colour (collect & resolve, lrt_collect4.inc / lrt_collect.inc),
-//                                                                   k_fwd_near (the 16-slot buffer's stale-slot rule, lrt_near.inc); k_trace<false> (legacy)
-//   DLT/optix_tracer/backward.cu:434-739   raygen + anyhit (bwd)  -> replay of the forward's hit record: k_bk_count / k_bk_scan / k_bk_base / k_bwd_prep2 /
+//   lib/utils/primitive_utils.py:182-224   build2DRectangle      -> fused into k_make_tree (quads are implicit)
+//   DLT/trace_surfels.cpp:46-148           OptiX GAS build        -> software LBVH in 5 launches: k_morton (+ digit histograms, 32-bit keys), own onesweep radix sort
+//                                                                   (lrt_radix.inc), k_make_tree (records + implicit 8-wide tree, lrt_build.inc; the top levels are
+//                                                                   finished by the forward's prologue k_fwd_init)
+//   DLT/optix_tracer/forward.cu:146-356    raygen + anyhit (fwd)  -> k_fwd_cr4 + k_fwd_colour (collect & resolve, lrt_collect4.inc / lrt_collect.inc; the colour pass is the
+//                                                                   forward's epilogue too), k_fwd_near (the 16-slot buffer's stale-slot rule, lrt_near.inc); k_trace<false> (legacy)
+//   DLT/optix_tracer/backward.cu:434-739   raygen + anyhit (bwd)  -> replay of the forward's hit record: k_bk_count / k_bk_scan / k_bwd_prep2 /
 //                                                                   k_bk_sort / k_bwd_reduce4 (lrt_bucket.inc, lrt_backward.inc); k_trace<true> re-traces
 //   DLT/trace_surfels.cpp:152-386          host launch code       -> lrt_forward / lrt_backward (stream-ordered, no host wait)
 //
