@@ -71,6 +71,13 @@ int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* sc
                        const float* opacities, float scale_modifier, int n_rays, const float* ray_o, const float* ray_d,
                        void* stream);
 
+/* The same for rays that are a (H, W) SLAB of a range image (a rank's azimuth sector; ray_o, ray_d (H,W,3)): besides the cone, the wedge
+ * between the planes of the slab's first and last column culls -- conservative for any ray set (the planes' margins are taken over all
+ * rays of the slab) -- so that a slab too wide for a cone (two or three ranks: 180 / 120 degrees) still builds only what it can reach. */
+int lrt_build_for_slab(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
+                       const float* opacities, float scale_modifier, int H, int W, const float* ray_o, const float* ray_d,
+                       void* stream);
+
 /* Refit: the LBVH of the last lrt_build (same P) keeps its primitive order and tree topology; records and boxes are
  * recomputed from the given (moved) parameters.  About 0.4x the cost of lrt_build; results do not depend on the order
  * (exhaustive traversal, hits sorted by (t, index)), only the traversal cost does as the primitives drift, so rebuild

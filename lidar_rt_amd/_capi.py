@@ -12,7 +12,7 @@ import os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
 
-EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_build_for_rays", "lrt_forward",
+EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_build_for_rays", "lrt_build_for_slab", "lrt_forward",
            "lrt_refit", "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_grad_gather", "lrt_grad_scatter_add",
            "lrt_owner_by_direction", "lrt_grad_pack_foreign", "lrt_grad_scatter_add_counted", "lrt_status_to_device",
            "lrt_grad_pack_touched", "lrt_grad_zero_rows_counted", "lrt_xchg_msg_words", "lrt_xchg_pack", "lrt_xchg_apply",
@@ -54,6 +54,8 @@ def load():
     lib.lrt_refit.argtypes = [vp, ci, vp, vp, vp, vp, cf, vp]
     lib.lrt_build_for_rays.restype = ci
     lib.lrt_build_for_rays.argtypes = [vp, ci, vp, vp, vp, vp, cf, ci, vp, vp, vp]
+    lib.lrt_build_for_slab.restype = ci
+    lib.lrt_build_for_slab.argtypes = [vp, ci, vp, vp, vp, vp, cf, ci, ci, vp, vp, vp]
     lib.lrt_forward.restype = ci
     lib.lrt_forward.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.lrt_backward.restype = ci

@@ -1248,7 +1248,7 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
 }
 
 static int build_impl(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots,
-                      const float* opac, float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_)
+                      const float* opac, float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_, int slab_H = 0, int slab_W = 0)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "%s: null state", fn);
     if (P < 0) LRT_FAIL(LRT_ERR_ARG, "%s: negative P", fn);
@@ -1268,7 +1268,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         unsigned* cone = nullptr;
         if (n_rays > 0) {                                        // cull against the cone around the given rays
             if (!st->cone) {
-                HIPCHK(hipMalloc(&st->cone, 16 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
+                HIPCHK(hipMalloc(&st->cone, 32 * sizeof(unsigned))); HIPCHK(hipMemset(st->cone, 0, 32 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
                 HIPCHK(hipEventCreateWithFlags(&st->cone_ev, hipEventDisableTiming));
             }
             cone = st->cone;
@@ -1278,7 +1278,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
                 st->cone_prev = st->cone_host[0];
             }
-            if (n_rays <= 131072) lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone);
+            if (n_rays <= 131072) lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W);
             else {
                 int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
                 lrt_launch(st->lrec, k_cone_init, dim3(1), dim3(64), 0, stream, cone);
@@ -1394,13 +1394,13 @@ static int rec_end(lrt_state* st, int rc, hipStream_t stream)
 }
 
 static int build_call(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod,
-                      int n_rays, const float* ray_o, const float* ray_d, void* stream_)
+                      int n_rays, const float* ray_o, const float* ray_d, void* stream_, int slab_H = 0, int slab_W = 0)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "%s: null state", fn);
     DeviceGuard dg(st->device);
     rec_begin(st, stream_);
     st->cone_ev_due = 0;
-    int rc = build_impl(fn, st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
+    int rc = build_impl(fn, st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_, slab_H, slab_W);
     rc = rec_end(st, rc, (hipStream_t)stream_);
     if (st->cone_ev_due) { st->cone_ev_due = 0; if (rc == LRT_OK) HIPCHK(hipEventRecord(st->cone_ev, (hipStream_t)stream_)); }
     return rc;
@@ -1445,6 +1445,13 @@ int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* sc
                        float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_)
 {
     return build_call("lrt_build_for_rays", st, P, means, scales, rots, opac, mod, n_rays, ray_o, ray_d, stream_);
+}
+
+int lrt_build_for_slab(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac,
+                       float mod, int H, int W, const float* ray_o, const float* ray_d, void* stream_)
+{
+    if (H < 0 || W < 0 || (long long)H * W > 0x7fffffffll) LRT_FAIL(LRT_ERR_ARG, "lrt_build_for_slab: bad slab size");
+    return build_call("lrt_build_for_slab", st, P, means, scales, rots, opac, mod, H * W, ray_o, ray_d, stream_, H, W);
 }
 
 static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t stream)
@@ -1593,7 +1600,12 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)
             // k_fwd_cr4: 8 waves per tile when every workgroup would get at most one tile anyway (few tiles: the launch lasts as
             // long as its heaviest tile), else 4
-            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 6 ? 8 : 4));
+            // Measured (round 4, tools/slab_timing.py with c4_waves forced): S1M 8192 / 4096 / 2048 / 1024 tiles: 4 waves win at 8192 (0.77 vs 0.87 ms),
+            // a draw at 4096, 8 waves win at 2048 (0.25-0.28 vs 0.31-0.33) and 1024; the 4 M Waymo shape (three times the hits per tile): 8 waves
+            // win at every tile count (10624 tiles: 2.35 vs 2.42 ms; 2656: 0.54 vs 0.73).  So: 8 waves for launches of up to 3072 tiles, and for
+            // any launch whose tiles composited >= 1024 hits on average in the last completed frame of this size.
+            const bool heavy_tiles = st->est_valid && st->est_hw == HW && (size_t)st->est_hits >= (size_t)1024 * (size_t)tp.n_tiles;
+            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : ((tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
             const int per_cu = nw == 8 ? (st->wg4_per_cu + 1) / 2 : st->wg4_per_cu;
             if (wg4 && tp.c4_qlimit < 64u * (unsigned)nw + 8u) tp.c4_qlimit = 64u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;

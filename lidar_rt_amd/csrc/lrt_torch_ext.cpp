@@ -137,6 +137,10 @@ void build_from_gaussians(State& st, const at::Tensor& means3D, const at::Tensor
         check_f32_cuda(ro_, "cull ray_o"); check_f32_cuda(rd_, "cull ray_d");
         const at::Tensor ro = ro_.detach().contiguous(), rd = rd_.detach().contiguous();
         TORCH_CHECK(ro.numel() == rd.numel() && rd.numel() % 3 == 0, "cull_rays must be two (...,3) tensors of the same size");
+        if (rd.dim() == 3 && rd.size(2) == 3 && ro.sizes() == rd.sizes())        // a (H, W, 3) slab of a range image: the wedge between its edge columns culls too
+            check_rc(lrt_build_for_slab(h, (int)P, fptr(m), fptr(s), fptr(r), fptr(o), (float)scale_modifier, (int)rd.size(0), (int)rd.size(1), fptr(ro), fptr(rd), stream),
+                     "lrt_build_for_slab");
+        else
         check_rc(lrt_build_for_rays(h, (int)P, fptr(m), fptr(s), fptr(r), fptr(o), (float)scale_modifier, (int)(rd.numel() / 3), fptr(ro), fptr(rd), stream),
                  "lrt_build_for_rays");
     }

@@ -255,9 +255,14 @@ def _ct_build_from_gaussians(state, means3D, scales, rotations, opacities, scale
             ro, rd = ro.detach().contiguous(), rd.detach().contiguous()
             if ro.numel() != rd.numel() or rd.numel() % 3:
                 raise RuntimeError("cull_rays must be two (...,3) tensors of the same size")
-            _capi.check(state._lib.lrt_build_for_rays(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
-                                                      float(scale_modifier), rd.numel() // 3, _capi.ptr(ro), _capi.ptr(rd),
-                                                      _stream_ptr()), "lrt_build_for_rays")
+            if rd.ndimension() == 3 and rd.size(2) == 3 and ro.shape == rd.shape:      # a (H, W, 3) slab: the wedge between its edge columns culls too
+                _capi.check(state._lib.lrt_build_for_slab(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
+                                                          float(scale_modifier), rd.size(0), rd.size(1), _capi.ptr(ro), _capi.ptr(rd),
+                                                          _stream_ptr()), "lrt_build_for_slab")
+            else:
+                _capi.check(state._lib.lrt_build_for_rays(h, P, _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o),
+                                                          float(scale_modifier), rd.numel() // 3, _capi.ptr(ro), _capi.ptr(rd),
+                                                          _stream_ptr()), "lrt_build_for_rays")
     state._dirty[idx] = False
     state._built_P[idx] = P
     state._built_mod[idx] = float(scale_modifier)

@@ -4,8 +4,9 @@
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI;
 "gloo" on CPU for the tests).  Every rank holds the full Gaussian set; rank r
 traces the contiguous column slab ``[r*W/N, (r+1)*W/N)`` of the (H, W) range
-image.  From 4 ranks on a rank's LBVH holds only the Gaussians its slab's ray
-cone can reach (``lrt_build_for_rays``; below that there is no useful cone).
+image.  A rank's LBVH holds only the Gaussians its slab can reach: the cone
+around its rays (useful from 4 ranks on) and the wedge between the planes of
+its edge columns (``lrt_build_for_slab``: what culls at 2 and 3 ranks).
 
 * forward : local slab -> ONE ``all_gather`` of ``[status | (H, W/N, 9) slab]``
   (4.7 MB at 64x2048) so every rank sees the whole image for image-space losses
@@ -144,7 +145,7 @@ class ShardedTracer:
         # queue.  Measured on S1M (tools/slab_timing.py, CULL=1, profiles/r03_summary.md): with the division-free cone test of round 3
         # the culled build is ahead from 4 ranks on (N=4: 0.265 -> 0.238 ms with a quarter of the Gaussians kept, N=8: 0.262 -> 0.182 ms
         # with an eighth); what is left is a chain of ~16 small launches.  A 180-degree slab (N=2) has no useful cone; 3 ranks: 120 degrees, none either.
-        self.cull_build = self.world >= 4
+        self.cull_build = self.world >= 2      # round 4: (H, W, 3) slabs are culled by the wedge between their edge columns as well (lrt_build_for_slab)
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
         if self.world > 1 and hasattr(self.backend, "defer_errors"):

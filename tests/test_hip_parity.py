@@ -652,10 +652,12 @@ def test_two_forwards_before_backward(s10k):
         assert rel_l2(t[k].grad.cpu().numpy().reshape(bw[k].shape), bw[k]) < 1e-3
 
 
-@pytest.mark.parametrize("n_slabs", [4, 8])
+@pytest.mark.parametrize("n_slabs", [2, 3, 4, 8])
 def test_ray_cone_culled_build_gives_the_same_results(n_slabs):
-    """lrt_build_for_rays (an N-way azimuth split builds the LBVH for its slab's rays only): conservative culling, so the
-    slab's image is bit-identical ((t, gidx) order) and the gradients agree up to summation order."""
+    """lrt_build_for_slab / lrt_build_for_rays (an N-way azimuth split builds the LBVH for its slab's rays only): conservative culling --
+    the cone around the rays and, for (H, W, 3) slabs, the wedge between the planes of the slab's edge columns (what is left at two or three
+    ranks, where a 180 / 120 degree slab has no useful cone) -- so the slab's image is bit-identical ((t, gidx) order) and the gradients
+    agree up to summation order."""
     from lidar_rt_amd.parallel import column_slab
     sc = scenes.make_scene(30000, seed=31, radius_scale=0.3)
     o, d = scenes.kitti_rays(16, 512)
@@ -676,7 +678,7 @@ def test_ray_cone_culled_build_gives_the_same_results(n_slabs):
                           scales=tt["scales"], rotations=tt["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
             out.backward(torch.as_tensor(g_, device="cuda:0"))
             kept = tr.optix_context.built_count(torch.device("cuda:0"))
-            assert 0 < kept < 0.75 * 30000, kept                               # something was actually left out
+            assert 0 < kept < (0.9 if n_slabs == 2 else 0.75) * 30000, kept    # something was actually left out (two ranks: about half plus the margins)
             np.testing.assert_array_equal(out.detach().cpu().numpy(), full["out"])
             assert rel_l2(acc.cpu().numpy(), full["accum"]) < 1e-6
             for k in GRADS:
