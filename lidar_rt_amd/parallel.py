@@ -145,7 +145,10 @@ class ShardedTracer:
         # queue.  Measured on S1M (tools/slab_timing.py, CULL=1, profiles/r03_summary.md): with the division-free cone test of round 3
         # the culled build is ahead from 4 ranks on (N=4: 0.265 -> 0.238 ms with a quarter of the Gaussians kept, N=8: 0.262 -> 0.182 ms
         # with an eighth); what is left is a chain of ~16 small launches.  A 180-degree slab (N=2) has no useful cone; 3 ranks: 120 degrees, none either.
-        self.cull_build = self.world >= 2      # round 4: (H, W, 3) slabs are culled by the wedge between their edge columns as well (lrt_build_for_slab)
+        # round 4: (H, W, 3) slabs are culled by the wedge between their edge columns as well (lrt_build_for_slab), which works at 2 and 3 ranks
+        # too -- and does not pay there (S1M, N=2: half the Gaussians kept, build 0.162 -> 0.227 ms: the culled path's cone kernel, compaction
+        # and unfused sort cost more than the smaller tree saves; forward unchanged).  So the default stays: from 4 ranks on
+        self.cull_build = self.world >= 4
         if os.environ.get("LRT_CULL_BUILD", "") in ("0", "1"):         # developer / test switch
             self.cull_build = os.environ["LRT_CULL_BUILD"] == "1"
         if self.world > 1 and hasattr(self.backend, "defer_errors"):

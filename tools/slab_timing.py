@@ -27,7 +27,7 @@ for N in NS:
         a, b = column_slab(W, r, N)
         o = torch.as_tensor(ro[:, a:b].copy(), device=dev); d = torch.as_tensor(rd[:, a:b].copy(), device=dev)
         g = dL[:, a:b].contiguous()
-        tr.cull_build = N >= int(os.environ.get("CULL_FROM", "2")) and os.environ.get("CULL", "0") == "1"
+        tr.cull_build = N >= int(os.environ.get("CULL_FROM", "4")) and os.environ.get("CULL", "0") == "1"
         be.state.enable_timing(True)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         n_it, n_warm = 8, 3
