@@ -190,6 +190,7 @@ struct lrt_state {
     LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
+    int colour_variant;  // 1 (default): four lanes per hit in k_fwd_colour when the SH table is (16, 3); 0: lane per hit (any table shape)
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
     int key32;           // 1 (default): 32-bit sort keys (Morton code >> 31) for builds that use the own radix sort
     int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
@@ -836,7 +837,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->colour_variant = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -921,6 +922,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
     if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
+    if (!strcmp(name, "colour_variant")) { st->colour_variant = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
@@ -1658,7 +1660,11 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
                 ScopedTimer tmc(st, 3, stream);                                                             // the colour pass by itself (inside the forward region's timer)
                 // the colour pass is the forward's epilogue as well (status words, hits beyond the record): no k_fwd_fin behind it (option fuse_fin)
-                lrt_launch(st->lrec, k_fwd_colour, dim3(cb), dim3(64), 0, stream, tp, st->fuse_fin ? st->ctrl : (unsigned*)nullptr, st->status_dev);
+                unsigned* const ctl_ = st->fuse_fin ? st->ctrl : (unsigned*)nullptr;
+                const int cv = (tp.nsh == 16 && tp.M == 16) ? st->colour_variant : 0;
+#define LRT_COL(Q_, G_, O_) lrt_launch(st->lrec, (k_fwd_colour<Q_, G_, O_>), dim3(cb), dim3(64), 0, stream, tp, ctl_, st->status_dev)
+                if (cv == 1) LRT_COL(true, 4, 4); else LRT_COL(false, 4, 4);      // tighter register caps for 5-8 waves per SIMD spill (measured: 0.87-0.93 ms forward against 0.734)
+#undef LRT_COL
                 fin_done = st->fuse_fin != 0;
             } else { tp.ovf_list = nullptr; }
         }
