@@ -181,6 +181,8 @@ struct lrt_state {
     // speculative sizing of the culled build: the sort and the tree are sized from the PREVIOUS culled build's kept count
     // (x1.25 + 4096), so that no read-back stalls the launch queue; cone_host = [kept, overflow] of the last build, valid after cone_ev
     hipEvent_t cone_ev; int cone_pending, cone_have_prev, cone_prev_P, spec_cull, cull_guess; unsigned cone_prev; int cone_flag_live;
+    int cone_seen;       // a culled build's count has reached the host at least once
+    int cull_next;       // sizing of the NEXT culled build, set by the caller who knows the ray set: > 0 speculative with this capacity, 0 read the count back, -1 the library's own rule
     unsigned* tile_counter;
     unsigned long long* stats;   // 8 counters
     int stats_enabled;
@@ -837,7 +839,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->fuse_fin = 1; st->colour_variant = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -886,6 +888,15 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
         {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec},
         {"graph", st->graph_mode}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
+    if (!strcmp(name, "cull_last")) {                        // primitives the last culled build kept (raw: also those a too small speculative size lost); -1 = none yet
+        DeviceGuard dg(st->device);
+        if (st->cone_pending) {                              // the count was copied right behind that build's k_morton_cull: normally long there
+            HIPCHK(hipEventSynchronize(st->cone_ev));
+            st->cone_pending = 0; st->cone_have_prev = (st->cone_host[1] == 0u); st->cone_prev = st->cone_host[0]; st->cone_seen = 1;
+        }
+        *value = st->cone_seen ? (int)st->cone_prev : -1;
+        return LRT_OK;
+    }
     LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: unknown option '%s'", name);
 }
 
@@ -914,6 +925,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "spec_margin")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: spec_margin must be >= 0"); st->spec_margin = value; return LRT_OK; }   // hits added to the speculated size (tests set 0)
     if (!strcmp(name, "spec_bwd")) { st->spec_bwd = value ? 1 : 0; return LRT_OK; }   // 0: the backward waits for the forward's hit count instead of speculating on it
     if (!strcmp(name, "spec_cull")) { st->spec_cull = value ? 1 : 0; st->cone_have_prev = 0; return LRT_OK; }   // 0: every culled build reads its count back
+    if (!strcmp(name, "cull_next")) { st->cull_next = value < 0 ? -1 : value; return LRT_OK; }   // see lrt_build_for_rays
     if (!strcmp(name, "cull_guess")) { st->cull_guess = value; return LRT_OK; }   // test hook: speculative size of the NEXT culled build
     if (!strcmp(name, "refine_ties")) { st->refine_ties = value ? 1 : 0; return LRT_OK; }   // 1 (default): hits closer than 2 ulp of t are ordered by their fp64 depth (needs the packed parameter lines of an unculled build); 0: by (t, gidx)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
@@ -1278,7 +1290,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 HIPCHK(hipEventSynchronize(st->cone_ev));        // copied right after its k_morton: long done
                 st->cone_pending = 0;
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
-                st->cone_prev = st->cone_host[0];
+                st->cone_prev = st->cone_host[0]; st->cone_seen = 1;
             }
             if (n_rays <= 131072) lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W);
             else {
@@ -1308,12 +1320,18 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
         unsigned keep_cap = (unsigned)P;
         bool spec = false, hist_fused = false, key32 = false;
-        if (cone && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
+        // The library's own rule trusts the previous build's count, i.e. assumes that consecutive culled builds see about the same ray set.  A
+        // caller whose ray sets change (training frames drawn at random from a drive) says what it knows instead (option cull_next): a capacity
+        // learnt from an earlier build for THESE rays, or 0 = unknown, read the count back.
+        if (cone && st->cull_next > 0) {
+            if ((unsigned long long)st->cull_next < (unsigned long long)P) { keep_cap = (unsigned)(st->cull_next < 64 ? 64 : st->cull_next); spec = true; }
+        } else if (cone && st->cull_next < 0 && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
             unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess
                                                         : (st->cone_prev + st->cone_prev / 4 + 4096ull);
             if (gsz < (unsigned long long)P) { keep_cap = (unsigned)(gsz < 64 ? 64 : gsz); spec = true; }
             st->cull_guess = 0;
         }
+        st->cull_next = -1;
         if (spec) HIPCHK(lrt_memset_async(st->lrec, st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
         if (cone) lrt_launch(st->lrec, k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
         else {
@@ -1340,7 +1358,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 HIPCHK(hipStreamSynchronize(stream));
                 Pk = (int)st->cone_host[0];
                 if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
-                st->cone_prev = (unsigned)Pk; st->cone_have_prev = 1;
+                st->cone_prev = (unsigned)Pk; st->cone_have_prev = 1; st->cone_seen = 1;
             }
         }
         st->cone_flag_live = spec ? 1 : 0;

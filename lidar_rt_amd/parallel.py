@@ -42,6 +42,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import collections
 import os
 import torch
 import torch.distributed as dist
@@ -178,6 +179,7 @@ class ShardedTracer:
         self._edges, self._edges_key = None, None      # column edges [0, .., W] of the current split (None: equal widths)
         self._step_no = 0
         self._t_events, self._t_last_ms, self._times = None, 0.0, None
+        self._cull_counts, self._cull_prev_key, self.cull_readbacks = collections.OrderedDict(), None, 0     # see _cull_sizing
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True):
@@ -309,15 +311,39 @@ class ShardedTracer:
             self._edges = edges
 
     # ---- forward ----------------------------------------------------------------------------------------------------------------
-    def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True):
+    def _cull_sizing(self, key):
+        """How the next ray-culled build is sized (library option cull_next).  The library can only guess from the PREVIOUS build's count,
+        which is right while consecutive builds see the same rays (a benchmark, a static sensor) and wrong when training draws frames at
+        random from a drive: the count of a sector can change several-fold from one pose to the next, a too small size loses primitives (a loud
+        error, code 8, but the optimizer step has happened by then).  So the counts are remembered PER RAY SET: a set seen before is sized
+        speculatively from its own last count (x 1.25 + 4096, no host wait), a new one reads its count back (one 8-byte copy: the host waits for
+        the build's first kernels once).  `key` identifies the ray set: the caller's cull_key (renderer: the frame index) or the identity of
+        the ray tensors, plus the slab and P."""
+        st = getattr(self.backend, "state", None)
+        if st is None or not hasattr(st, "get_option") or not self._dev.type == "cuda":
+            return
+        if self._cull_prev_key is not None:
+            n = st.get_option("cull_last", self._dev)          # copied behind that build's first kernels: long on the host
+            if n >= 0:
+                self._cull_counts[self._cull_prev_key] = n
+                self._cull_counts.move_to_end(self._cull_prev_key)
+                while len(self._cull_counts) > 16384:
+                    self._cull_counts.popitem(last=False)
+        g = self._cull_counts.get(key)
+        st.set_option("cull_next", 0 if g is None else g + g // 4 + 4096)
+        self._cull_prev_key = key
+        self.cull_readbacks += 1 if g is None else 0
+
+    def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True, cull_key=None):
         H, W = ray_o.shape[:2]
         self._dev = means.device
         if self.world > 1 or self.force_collectives:
             self.check(wait=True)                              # statuses and counts of the previous step: long there; all ranks agree
         timed = self.balance and self.world > 1 and means.is_cuda and W >= 16 * self.world
         if timed:
-            if self._t_events is not None and self._t_events[1].query():
-                self._t_last_ms = float(self._t_events[0].elapsed_time(self._t_events[1]))
+            if self._t_events is not None and self._t_events[3].query():
+                e = self._t_events                             # the rank's OWN work: build + forward, and the local backward -- not the slab
+                self._t_last_ms = float(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]))     # all_gather between them, which waits for the slowest rank
             self._step_no += 1
             if self._step_no % self.balance_every == 0:
                 self._rebalance(W)
@@ -327,6 +353,9 @@ class ShardedTracer:
         self._ro = ray_o[:, a:b].contiguous(); self._rd = ray_d[:, a:b].contiguous()
         self._rays_full = (ray_o, ray_d)
         cull = (self._ro, self._rd) if self.cull_build else None
+        if cull is not None:
+            ident = cull_key if cull_key is not None else (ray_o.data_ptr(), ray_o._version, ray_d.data_ptr(), ray_d._version, tuple(ray_o.shape))
+            self._cull_sizing((ident, a, b, int(means.shape[0])))
         if rebuild or cull is not None:                        # a ray-culled structure must be rebuilt for every ray set
             if self._backend_takes(self.backend.build, "cull_rays"):
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)
@@ -335,6 +364,8 @@ class ShardedTracer:
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
         self._out_loc, self._accum_loc = out_loc, accum_loc
+        if timed:
+            evf = torch.cuda.Event(enable_timing=True); evf.record()
         # what backward() needs of THIS forward: an autograd Function keeps it in its ctx (renderer._ShardedTrace), so that a second
         # forward before loss.backward() -- an evaluation render, another frame -- cannot make the backward differentiate the wrong slab
         self.last_ctx = {"slab": (a, b), "ro": self._ro, "rd": self._rd, "out_loc": out_loc, "accum_loc": accum_loc,
@@ -342,7 +373,7 @@ class ShardedTracer:
         if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
         # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
-        self._timed_ev0 = ev0 if timed else None
+        self._timed_ev0 = (ev0, evf) if timed else None
         with self._Region(self, "slab_all_gather", out_loc.device):
             wmax = max(self.slab_of(W, r)[1] - self.slab_of(W, r)[0] for r in range(self.world))
             msg = torch.zeros(2 + H * wmax * 9, dtype=out_loc.dtype, device=out_loc.device)
@@ -372,6 +403,8 @@ class ShardedTracer:
         a, b = fc["slab"]
         ro_, rd_, out_loc_, accum_loc_ = fc["ro"], fc["rd"], fc["out_loc"], fc["accum_loc"]
         dL = dL_full[:, a:b].contiguous()
+        if getattr(self, "_timed_ev0", None) is not None:
+            evb0 = torch.cuda.Event(enable_timing=True); evb0.record()
         P = means.shape[0]; M = shs.shape[1]
         lay = getattr(self, "_layout", None)
         if lay is None or lay.P != P or lay.M != M or lay.flat.device != means.device:
@@ -403,7 +436,7 @@ class ShardedTracer:
                 direct[k].copy_(g[k].view_as(direct[k]))
         if getattr(self, "_timed_ev0", None) is not None:          # this rank's own compute of the step ends here (the exchange is not the rank's work)
             ev1 = torch.cuda.Event(enable_timing=True); ev1.record()
-            self._t_events = (self._timed_ev0, ev1); self._timed_ev0 = None
+            self._t_events = (self._timed_ev0[0], self._timed_ev0[1], evb0, ev1); self._timed_ev0 = None
         self.last_exchange = None
         if not exchanging:
             if pz:                                             # leave this step's own list behind for the next step's clearing

@@ -44,11 +44,11 @@ class _ShardedTrace(torch.autograd.Function):
     forward and the complete ones in the backward (train.py:215-220 reads them after loss.backward())."""
 
     @staticmethod
-    def forward(ctx, st, ray_o, ray_d, means3D, scales, rotations, opacity, shs, deg, bg, accum_out):
+    def forward(ctx, st, ray_o, ray_d, means3D, scales, rotations, opacity, shs, deg, bg, accum_out, cull_key=None):
         if st.world > 1 and st.exchange == "owner":
             raise ValueError("renderer.sharded needs a replicated gradient exchange ('sparse', 'dense' or 'auto'), not 'owner'")
         a = [t.detach().contiguous() for t in (means3D, scales, rotations, opacity, shs)]
-        out, accum_loc = st.forward(ray_o.contiguous(), ray_d.contiguous(), a[0], a[1], a[2], a[3], a[4], int(deg), bg)
+        out, accum_loc = st.forward(ray_o.contiguous(), ray_d.contiguous(), a[0], a[1], a[2], a[3], a[4], int(deg), bg, cull_key=cull_key)
         accum_out.copy_(accum_loc.reshape(accum_out.shape))
         ctx.st, ctx.deg, ctx.bg, ctx.accum_out = st, int(deg), bg, accum_out
         ctx.fwd = st.last_ctx          # this forward's slab, rays, local output and record serial (a later forward must not replace them)
@@ -62,7 +62,7 @@ class _ShardedTrace(torch.autograd.Function):
         ctx.accum_out.copy_(g["accum"].reshape(ctx.accum_out.shape))
         # the views belong to a buffer the next step reuses: hand autograd its own copies
         return (None, None, None, g["means"].clone(), g["scales"].clone(), g["rotations"].clone(),
-                g["opacities"].reshape(opacity.shape).clone(), g["shs"].clone(), None, None, None)
+                g["opacities"].reshape(opacity.shape).clone(), g["shs"].clone(), None, None, None, None)
 
 
 def _fused_inputs(frame, assets, dynamic, decomp):
@@ -147,7 +147,8 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
         # this rank's azimuth slab + collectives (build, trace and exchange inside ShardedTracer); same outputs on every rank
         accum = torch.zeros(means3D.shape[0], dtype=torch.float32, device=means3D.device)
         rendered = _ShardedTrace.apply(sharded, rays_o, rays_d, means3D, scales, rotations, opacity, shs,
-                                       gaussian_assets[0].active_sh_degree, settings.bg, accum)
+                                       gaussian_assets[0].active_sh_degree, settings.bg, accum,
+                                       ("frame", frame, decomp) if isinstance(frame, (int, str)) else None)      # the ray set's name: sizes the culled build (ShardedTracer._cull_sizing)
     else:
         # fused replacement of primitiveCallback(...) + tracer.build_acceleration_structure(vertices, faces, rebuild=True)
         tracer_2dgs.build_from_gaussians(means3D, scales, rotations, opacity)

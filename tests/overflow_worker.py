@@ -29,7 +29,10 @@ def main():
     log = []
     for step in range(6):
         if step == 3 and rank == 1:
-            tr.backend.state.set_option("cull_guess", 64)      # this rank's speculatively sized culled build loses primitives
+            sizing = tr._cull_sizing                           # this rank's culled build is sized far too small once: it loses primitives
+            def too_small(key, _orig=sizing):
+                _orig(key); tr.backend.state.set_option("cull_next", 64); tr._cull_sizing = _orig
+            tr._cull_sizing = too_small
         try:
             out, _ = tr.forward(ro, rd, *args)
             tr.backward(*args, g_up)

@@ -117,3 +117,42 @@ def test_sharded_training_steps_on_one_gpu_match_the_single_rank_run(tmp_path):
         scale = max(np.abs(b).max(), 1.0)
         assert (np.abs(a - b) > 1e-5 * scale).mean() < 2e-3, (k, float(np.abs(a - b).max()))
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-4, k
+
+
+def test_culled_builds_survive_ray_sets_whose_kept_count_changes_severalfold():
+    """A rank's sector keeps very different numbers of Gaussians from pose to pose (training frames drawn at random from a drive).  The
+    culled build of a ray set seen before is sized from ITS OWN last count, a new one reads its count back (ShardedTracer._cull_sizing):
+    alternating a narrow and a wide sector -- kept counts an order of magnitude apart -- must neither lose primitives (error code 8) nor
+    change the results, and must read back exactly once per ray set."""
+    sys.path.insert(0, REPO)
+    import numpy as np
+    from lidar_rt_amd import scenes
+    from lidar_rt_amd.parallel import ShardedTracer
+    dev = torch.device("cuda", 0)
+    sc = scenes.make_scene(120_000, seed=5, radius_scale=0.4)
+    o, d = scenes.kitti_rays(16, 512)
+    t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
+    bg = torch.as_tensor(scenes.BG_DEFAULT, device=dev)
+    dL = torch.as_tensor(scenes.upstream_grad(16, 512), device=dev)
+    args = (t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+    slabs = {"narrow": (0, 32), "wide": (128, 384)}
+    rays = {k: (torch.as_tensor(o[:, a:b].copy(), device=dev), torch.as_tensor(d[:, a:b].copy(), device=dev), dL[:, a:b].contiguous()) for k, (a, b) in slabs.items()}
+    ref = {}
+    plain = ShardedTracer()
+    for k, (ro, rd, g) in rays.items():
+        out, _ = plain.forward(ro, rd, *args)
+        ref[k] = (out.clone(), {n: v.clone() for n, v in plain.backward(*args, g).items()})
+    tr = ShardedTracer(); tr.cull_build = True
+    kept = {}
+    for rep in range(3):
+        for k, (ro, rd, g) in rays.items():
+            out, _ = tr.forward(ro, rd, *args, cull_key=k)
+            gr = tr.backward(*args, g)
+            torch.cuda.synchronize()
+            kept[k] = tr.backend.state.built_count(dev)
+            assert torch.equal(out, ref[k][0]), (rep, k)
+            for n in ("means", "shs", "opacities"):
+                assert torch.allclose(gr[n], ref[k][1][n], rtol=1e-5, atol=1e-7 * float(ref[k][1][n].abs().max())), (rep, k, n)
+    tr.forward(rays["narrow"][0], rays["narrow"][1], *args, cull_key="narrow")     # the check of the last wide step happens here
+    assert kept["wide"] > 3 * kept["narrow"], kept
+    assert tr.cull_readbacks == 2, tr.cull_readbacks

@@ -33,7 +33,7 @@ for N in NS:
         n_it, n_warm = 8, 3
         for it in range(n_it):
             if it == n_warm: be.state.get_timing(dev); ev[0].record()          # drop the warm-up samples
-            tr.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg)
+            tr.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, cull_key=(N, r))
             tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, g)
         ev[1].record()
         torch.cuda.synchronize()
