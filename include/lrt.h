@@ -65,7 +65,9 @@ int lrt_build(lrt_state* st, int P, const float* means, const float* scales, con
  * reference): Gaussians whose bounding sphere lies outside the cone around the rays are left out of the LBVH (conservative:
  * results are unchanged).  ray_o, ray_d (n_rays,3).  The sort and the tree are sized by the kept count: the FIRST culled build of a
  * given P reads it back (one 8-byte device->host copy, a host wait); later ones are sized speculatively from the previous build's
- * count (x 1.25 + 4096) without a wait, and primitives that did not fit raise error bit 8 in the next forward (option spec_cull=0
+ * count (x 1.25 + 4096) without a wait -- that assumes consecutive culled builds see about the same rays; a caller whose ray sets change
+ * says what it knows with lrt_set_option("cull_next", N): N > 0 = capacity for the next culled build, 0 = read the count back;
+ * lrt_get_option("cull_last") returns what the last culled build kept -- and primitives that did not fit raise error bit 8 in the next forward (option spec_cull=0
  * restores the read-back).  Cones wider than ~80 degrees keep everything. */
 int lrt_build_for_rays(lrt_state* st, int P, const float* means, const float* scales, const float* rotations,
                        const float* opacities, float scale_modifier, int n_rays, const float* ray_o, const float* ray_d,
