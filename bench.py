@@ -393,7 +393,7 @@ def main():
                     step_traffic = pj["step"]["corrected_bytes_per_step"]; step_traffic_raw = pj["step"]["raw_bytes_per_step"]
                     cr4 = [k for k in kern if k.startswith("k_fwd_cr4") and kern[k]["region"] == "forward"]
                     valu = max((kern[k].get("valu_issue_frac", 0.0) for k in cr4), default=None)
-                    src_rows = {"k_fwd_cr4": cr4, "k_fwd_colour": ["k_fwd_colour"], "backward": regs["backward"]["kernels"], "build": regs["build"]["kernels"]}
+                    src_rows = {"k_fwd_cr4": cr4, "k_fwd_colour": [k for k in kern if k.startswith("k_fwd_colour")], "backward": regs["backward"]["kernels"], "build": regs["build"]["kernels"]}
                     for name, ks in src_rows.items():
                         ks = [k for k in ks if k in kern and kern[k]["launches_per_step"]]
                         corr = sum(kern[k]["corrected_bytes_per_launch"] * kern[k]["launches_per_step"] for k in ks)

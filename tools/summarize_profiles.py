@@ -60,7 +60,8 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.2f},"
                 f"{r['Percentage']},{float(r['MinNs'])/1e3:.2f},{float(r['MaxNs'])/1e3:.2f}\n")
 stat = {short(r["Name"]): {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in rows}
-steps_stat = stat.get("k_fwd_colour", {}).get("calls", 0)
+COLOUR = next((k for k in stat if k.startswith("k_fwd_colour")), "k_fwd_colour")      # the colour pass runs once per step (a template since round 4: `k_fwd_colour<true, 4, 4>`)
+steps_stat = stat.get(COLOUR, {}).get("calls", 0)
 
 pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
@@ -84,7 +85,8 @@ def avg(k, n):
     return c[n][0] / c[n][1] if n in c and c[n][1] else None
 
 
-steps_pmc = {n: pmc["k_fwd_colour"][n][1] for n in ("FETCH_SIZE", "WRITE_SIZE") if n in pmc["k_fwd_colour"]}
+COLOUR_P = next((k for k in pmc if k.startswith("k_fwd_colour")), "k_fwd_colour")
+steps_pmc = {n: pmc[COLOUR_P][n][1] for n in ("FETCH_SIZE", "WRITE_SIZE") if n in pmc[COLOUR_P]}
 kernels = {}
 for k in pmc:
     fs, ws = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
