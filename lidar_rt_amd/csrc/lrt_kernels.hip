@@ -748,7 +748,8 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
         lrt_launch(st->lrec, k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
-                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top);
+                           st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top,
+                           kept_ptr ? st->cone_host : (unsigned*)nullptr);
         if (st->fused_tree == 2 && L >= 4) lrt_launch(st->lrec, k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
         else if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
         return LRT_OK;
@@ -1319,7 +1320,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
         // count + 4096; the unused tail holds sentinel keys (sorted last, turned into padding by k_make_records) and the actual count
         // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
         unsigned keep_cap = (unsigned)P;
-        bool spec = false, hist_fused = false, key32 = false;
+        bool spec = false, hist_fused = false, key32 = false; const unsigned* sort_nv = nullptr; int own_limit = LRT_BUILD_MERGE_LIMIT;
         // The library's own rule trusts the previous build's count, i.e. assumes that consecutive culled builds see about the same ray set.  A
         // caller whose ray sets change (training frames drawn at random from a drive) says what it knows instead (option cull_next): a capacity
         // learnt from an earlier build for THESE rays, or 0 = unknown, read the count back.
@@ -1332,9 +1333,29 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             st->cull_guess = 0;
         }
         st->cull_next = -1;
-        if (spec) HIPCHK(lrt_memset_async(st->lrec, st->keys_a, 0xff, (size_t)keep_cap * sizeof(uint64_t), stream));
-        if (cone) lrt_launch(st->lrec, k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack);
-        else {
+        if (cone) {
+            // a speculatively sized culled build knows the number of sorted keys (keep_cap) before the launch: its own sort's digit histograms
+            // are counted by k_morton_cull and its keys are 32 bits wide, like the unculled build's (the read-back path sizes the sort after
+            // the kernel: it keeps the histogram launch and 64-bit keys)
+            int sb_ = 0;
+            if (spec) {
+                int pb_ = 1; while ((1ll << pb_) < (long long)keep_cap) pb_++;
+                sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
+                // with the histogram counted by k_morton_cull and no sentinel fill the own sort beats rocPRIM's merge sort well below the limit of
+                // the unculled build (a rank of 8 on S1M sorts 117 k keys: build 0.128 -> 0.115 ms)
+                own_limit = 32768;
+                const bool own = st->own_sort == 1 || (st->own_sort == 2 && ((int)keep_cap >= own_limit || st->graph_mode));
+                hist_fused = st->fused_hist && own;
+                key32 = st->key32 && own && LRT_SORT_LO_BIT == 31;
+                if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
+                // the slots behind the kept keys must sort last: the own sort's first pass reads them as all-ones by the kept count (no fill
+                // launch); rocPRIM's sort needs the sentinel keys in memory
+                if (!(own && hist_fused)) HIPCHK(lrt_memset_async(st->lrec, st->keys_a, 0xff, (size_t)keep_cap * (key32 ? sizeof(uint32_t) : sizeof(uint64_t)), stream));
+                else sort_nv = cone + 10;
+            }
+            lrt_launch(st->lrec, k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack,
+                       hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb_ : 63 - sb_, key32 ? 32 : 63, key32 ? 1 : 0);
+        } else {
             // own onesweep next (decided below by the same rule) and fused_hist: k_morton counts the sort's digit histograms on the way
             int pb_ = 1; while ((1ll << pb_) < (long long)P) pb_++;
             int sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
@@ -1347,7 +1368,9 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                                hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb_ : 63 - sb_, key32 ? 32 : 63, key32 ? 1 : 0);
         }
         if (cone) {
-            HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            // the kept count travels to the host for the next build's sizing: k_make_tree stores it into the pinned words itself when the build
+            // is speculative and the fused tree kernel runs; otherwise an 8-byte copy behind k_morton_cull
+            if (!(spec && st->fused_tree)) HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             st->cone_prev_P = P;
             if (spec) {
                 st->cone_ev_due = 1;                             // recorded by the caller once this call's launches have been issued
@@ -1368,7 +1391,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
             int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
             int sort_bits = ((pbits + st->morton_extra + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
-            if (st->own_sort == 1 || (st->own_sort == 2 && (Pk >= LRT_BUILD_MERGE_LIMIT || st->graph_mode))) {      // below the limit rocPRIM's merge sort needs fewer launches (replayed from a graph the launches cost nothing: own sort)
+            if (st->own_sort == 1 || (st->own_sort == 2 && (Pk >= own_limit || st->graph_mode))) {      // below the limit rocPRIM's merge sort needs fewer launches (replayed from a graph the launches cost nothing: own sort)
                 // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
                 int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
                 HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
@@ -1376,9 +1399,9 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 if (key32) {                                               // k_morton wrote 32-bit keys (code >> 31) into the key buffer
                     uint32_t* kr32 = nullptr;
                     HIPCHK((rs_sort<uint32_t, true, 8>(st->sort_build, reinterpret_cast<uint32_t*>(st->keys_a), reinterpret_cast<uint32_t*>(st->keys_b), st->vals_a, st->vals_b,
-                                                       (unsigned)Pk, 32 - sb, 32, stream, &kr32, &vr, hist_fused, st->lrec)));
+                                                       (unsigned)Pk, 32 - sb, 32, stream, &kr32, &vr, hist_fused, st->lrec, sort_nv)));
                 } else
-                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec)));
+                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec, sort_nv)));
                 if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
             } else {
                 HIPCHK(lrt_rec_flush(st->lrec, stream));                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
