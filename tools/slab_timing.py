@@ -32,16 +32,25 @@ for N in NS:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         n_it, n_warm = 8, 3
         for it in range(n_it):
-            if it == n_warm: be.state.get_timing(dev); ev[0].record()          # drop the warm-up samples
+            if it == n_warm: be.state.get_timing(dev); ev[0].record()     # drop the warm-up samples
             tr.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, cull_key=(N, r))
             tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, g)
         ev[1].record()
         torch.cuda.synchronize()
         tm = be.state.get_timing(dev)
+        # the whole step once more WITHOUT the library's region timers (8 event records per step on the launch stream cost 30-40 us at N=8)
+        be.state.enable_timing(False)
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for it in range(n_it + 4):
+            if it == n_warm: ev2[0].record()
+            tr.forward(o, d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, cull_key=(N, r))
+            tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], 3, bg, g)
+        ev2[1].record(); torch.cuda.synchronize()
+        whole = ev2[0].elapsed_time(ev2[1]) / (n_it + 4 - n_warm)
         f = lambda k: tm[k][0] / max(tm[k][1], 1)
         kept = be.state.built_count(dev)
         print(f"N={N} rank {r}: cols {b - a:4d}  kept {kept:7d}  build {f('build'):.3f}  fwd {f('fwd'):.3f}  bwd {f('bwd'):.3f}  sum {f('build') + f('fwd') + f('bwd'):.3f} ms"
-              f"   whole per-rank step (events around build + forward + backward + list bookkeeping): {ev[0].elapsed_time(ev[1]) / (n_it - n_warm):.3f} ms")
+              f"   whole per-rank step (events around build + forward + backward + list bookkeeping): {whole:.3f} ms (with the library's region timers on: {ev[0].elapsed_time(ev[1]) / (n_it - n_warm):.3f})")
 
 # ---- local cost of the owner-based gradient exchange for one rank (owner map + listing / packing of the foreign rows), and how
 # many rows a rank would send: the network leg itself cannot be measured on one GPU
