@@ -145,6 +145,7 @@ def main():
                     "graph launch per lrt_build / lrt_forward / lrt_backward).  The step then runs on a side stream (the legacy default stream cannot be captured) and "
                     "without the library's HIP-event timers (phase_ms / roofline per-kernel times are null).  What it buys is host launch time: S10k is launch-bound")
     ap.add_argument("--no-build-in-step", action="store_true", help="exclude the LBVH rebuild from the step")
+    ap.add_argument("--time-every", type=int, default=8, help="the library's region timers record their HIP events on every K-th step of the timed window (1 = every step)")
     ap.add_argument("--no-stats-step", action="store_true", help="skip the one instrumented (untimed) step that collects the traversal counters: the profiling "
                     "scripts use it so that every kernel of the trace is a kernel of a regular step (the counters' k_fwd_cr4<.., true> instantiation is not)")
     ap.add_argument("--refit-every", type=int, default=0, help="K > 0: K lrt_refit calls between full LBVH builds (NOT the headline "
@@ -254,8 +255,11 @@ def main():
         if world > 1:
             tr_ = torch.tensor([reps], dtype=torch.int64, device=dev); dist.all_reduce(tr_, op=dist.ReduceOp.MAX); reps = int(tr_.item())
     steps_run = args.steps * reps
-    st.enable_timing(not args.graph)                                  # the library's timers record events between kernels: not inside a graph
-    tr.enable_phase_timing(True)
+    # the library's region timers (HIP events on the launch stream around build / forward / colour pass / backward) run INSIDE the timed window,
+    # on every 8th step: an event record between two kernels costs ~5 us of pipeline, eight per step were 3-5 % of the step they measure
+    st.set_option("timing_every", max(1, args.time_every))
+    st.enable_timing(not args.graph)                                  # (they record events between kernels: not inside a graph)
+    tr.enable_phase_timing(True, every=max(1, args.time_every))
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps_run):

@@ -192,6 +192,7 @@ struct lrt_state {
     LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
+    int timing_every; unsigned timer_calls[4];      // see ScopedTimer
     int colour_variant;  // 1 (default): four lanes per hit in k_fwd_colour when the SH table is (16, 3); 0: lane per hit (any table shape)
     int fuse_fin;        // 1 (default): k_fwd_colour is the forward's epilogue too (no k_fwd_fin launch behind a deferred-colour forward)
     int key32;           // 1 (default): 32-bit sort keys (Morton code >> 31) for builds that use the own radix sort
@@ -807,6 +808,9 @@ struct ScopedTimer {
     ScopedTimer(lrt_state* s, int kind, hipStream_t str) : st(s), stream(str)
     {
         if (!st->timing_enabled || kind < 0) return;
+        // option timing_every = K: only every K-th call of a kind is timed -- an event record between two kernels costs ~5 us of pipeline on the
+        // launch stream, eight of them per step are 3-5 % of an S1M step
+        if (kind < 4 && st->timing_every > 1 && (st->timer_calls[kind]++ % (unsigned)st->timing_every) != 0u) return;
         if (st->timers_used == st->timers->size()) {
             lrt_state::TimerSlot t; t.kind = kind;
             if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
@@ -840,7 +844,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -935,6 +939,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
     if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
+    if (!strcmp(name, "timing_every")) { st->timing_every = value < 1 ? 1 : value; memset(st->timer_calls, 0, sizeof(st->timer_calls)); return LRT_OK; }
     if (!strcmp(name, "colour_variant")) { st->colour_variant = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)

@@ -185,12 +185,17 @@ class ShardedTracer:
         self._cull_counts, self._cull_prev_key, self.cull_readbacks = collections.OrderedDict(), None, 0     # see _cull_sizing
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
-    def enable_phase_timing(self, on: bool = True):
-        self._phase_on = bool(on); self._phase_ev = []
+    def enable_phase_timing(self, on: bool = True, every: int = 1):
+        """HIP events around the collective regions; every = K: only every K-th call of a region is timed (an event record between two
+        kernels costs ~5 us of pipeline on the stream)."""
+        self._phase_on = bool(on); self._phase_ev = []; self._phase_every = max(1, int(every)); self._phase_calls = {}
 
     class _Region:
         def __init__(self, owner, name, device):
             self.o, self.name, self.cuda = owner, name, (device.type == "cuda" and owner._phase_on)
+            if self.cuda and getattr(owner, "_phase_every", 1) > 1:
+                c = owner._phase_calls.get(name, 0); owner._phase_calls[name] = c + 1
+                self.cuda = (c % owner._phase_every) == 0
         def __enter__(self):
             if self.cuda:
                 self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True); self.a.record()
