@@ -2,14 +2,15 @@
 """Developer tool: where does the HOST time of one rank's step go?  cProfile over the enqueue loop of a rank of an N-way split (no device wait
 inside the loop); the GPU step of a rank of 8 is 0.4 ms, the host must stay below it.  env SLAB_N (8), WORKLOAD, STEPS (200)"""
 import cProfile, os, pstats, sys, time
-os.environ.setdefault("LRT_PREZERO", "force")
+if os.environ.get("SLAB_N", "8") != "1": os.environ.setdefault("LRT_PREZERO", "force")
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
 from lidar_rt_amd import scenes
 from lidar_rt_amd.parallel import ShardedTracer, column_slab
 
 dev = torch.device("cuda:0")
-sc, ro, rd = scenes.waymo_dynamic_4m() if os.environ.get("WORKLOAD", "s1m") == "waymo4m" else scenes.s1m()
+wl = os.environ.get("WORKLOAD", "s1m")
+sc, ro, rd = scenes.waymo_dynamic_4m() if wl == "waymo4m" else scenes.s10k() if wl == "s10k" else scenes.s1m()
 t = {k: torch.as_tensor(v, device=dev) for k, v in sc.items()}
 H, W = ro.shape[:2]
 N = int(os.environ.get("SLAB_N", "8")); steps = int(os.environ.get("STEPS", "200"))
