@@ -361,7 +361,11 @@ class ShardedTracer:
             self._step_no += 1
             if self._step_no % self.balance_every == 0:
                 self._rebalance(W)
-            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
+            # the rank's time is MEASURED on the step behind a rebalance only (and until a first measurement exists): four event records on
+            # the launch stream cost ~20 us, 5 % of a rank's 0.36 ms step at N=8; the last measured time travels with every slab message
+            measure = (self._step_no % self.balance_every == 0) or self._t_events is None
+            if measure:
+                ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
         a, b = self.slab_of(W, self.rank)
         self._slab = (a, b)
         self._ro = ray_o[:, a:b].contiguous(); self._rd = ray_d[:, a:b].contiguous()
@@ -378,7 +382,7 @@ class ShardedTracer:
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
         self._out_loc, self._accum_loc = out_loc, accum_loc
-        if timed:
+        if timed and measure:
             evf = torch.cuda.Event(enable_timing=True); evf.record()
         # what backward() needs of THIS forward: an autograd Function keeps it in its ctx (renderer._ShardedTrace), so that a second
         # forward before loss.backward() -- an evaluation render, another frame -- cannot make the backward differentiate the wrong slab
@@ -387,7 +391,7 @@ class ShardedTracer:
         if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
         # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
-        self._timed_ev0 = (ev0, evf) if timed else None
+        self._timed_ev0 = (ev0, evf) if (timed and measure) else None
         with self._Region(self, "slab_all_gather", out_loc.device):
             wmax = max(self.slab_of(W, r)[1] - self.slab_of(W, r)[0] for r in range(self.world))
             msg = torch.zeros(2 + H * wmax * 9, dtype=out_loc.dtype, device=out_loc.device)
