@@ -424,6 +424,7 @@ def main():
                 "valu_issue_frac": valu,
                 "algorithmic_bytes_per_ray": {"fwd": bf, "bwd": bb, "C": C, "K": K, "source": ck_src},
                 "avg_kernel_ms": {"build_region": ms_build, "trace_fwd": ms_f, "trace_bwd": ms_b, "colour_pass": ms_c},
+                "avg_kernel_ms_note": f"HIP events on the launch stream inside the timed window, recorded on every {max(1, args.time_every)}. step of it ({kt['fwd'][1]} forward launches timed)",
                 # per kernel / region: algorithmic bytes (SURVEY 8(d) split), live HIP-event time of this run, and -- from the committed
                 # profile of the same sources -- counter bytes (corrected / raw), rocprofv3 kernel time and the fractions of 8 TB/s
                 "per_kernel": per_kernel,
