@@ -334,7 +334,7 @@ class ShardedTracer:
         the build's first kernels once).  `key` identifies the ray set: the caller's cull_key (renderer: the frame index) or the identity of
         the ray tensors, plus the slab and P."""
         st = getattr(self.backend, "state", None)
-        if st is None or not hasattr(st, "get_option") or not self._dev.type == "cuda":
+        if st is None or not hasattr(st, "get_option"):
             return
         if self._cull_prev_key is not None:
             n = st.get_option("cull_last", self._dev)          # copied behind that build's first kernels: long on the host

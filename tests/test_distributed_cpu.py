@@ -108,3 +108,37 @@ def test_sharded_training_steps_equal_the_single_rank_run(tmp_path, world, excha
             np.testing.assert_allclose(res[k], single[k], rtol=0, atol=1e-6 * max(np.abs(single[k]).max(), 1.0))
         if first_cap:
             assert int(res["reruns"][0]) >= 1, "the undersized first exchange must have been re-run"
+
+
+def test_culled_builds_are_sized_per_ray_set():
+    """ShardedTracer._cull_sizing (the policy, against a stand-in for the library state): a ray set seen for the first time reads its
+    count back (cull_next = 0), a known one is sized from ITS OWN last count x 1.25 + 4096 whatever the build in between kept, and the
+    table forgets the oldest sets first."""
+    import torch
+    from lidar_rt_amd.parallel import ShardedTracer
+
+    class State:
+        def __init__(self): self.last, self.next = -1, None
+        def get_option(self, name, dev=None): assert name == "cull_last"; return self.last
+        def set_option(self, name, v): assert name == "cull_next"; self.next = v
+
+    class Backend:
+        def __init__(self): self.state = State()
+
+    tr = ShardedTracer(backend=Backend())
+    tr._dev = torch.device("cpu")
+    st = tr.backend.state
+    tr._cull_sizing("A"); assert st.next == 0 and tr.cull_readbacks == 1          # unknown: read back
+    st.last = 100_000                                                              # ... that build kept 100 k
+    tr._cull_sizing("B"); assert st.next == 0 and tr.cull_readbacks == 2          # another set: read back, and A's count is learnt
+    st.last = 900_000
+    tr._cull_sizing("A"); assert st.next == 100_000 + 25_000 + 4096               # A again: its own count, not B's 900 k
+    st.last = 101_000
+    tr._cull_sizing("B"); assert st.next == 900_000 + 225_000 + 4096
+    tr._cull_sizing("A"); assert st.next == 101_000 + 25_250 + 4096               # refreshed by its last build
+    assert tr.cull_readbacks == 2
+    for i in range(17000):                                                         # the table is bounded: the oldest sets go first
+        tr._cull_counts[("x", i)] = 1
+    st.last = 5
+    tr._cull_sizing("C")
+    assert len(tr._cull_counts) <= 16384 and "B" not in tr._cull_counts
