@@ -142,3 +142,34 @@ def test_culled_builds_are_sized_per_ray_set():
     st.last = 5
     tr._cull_sizing("C")
     assert len(tr._cull_counts) <= 16384 and "B" not in tr._cull_counts
+
+
+def test_slab_balancer_moves_edges_towards_equal_time_and_keeps_the_tiling():
+    """ShardedTracer._rebalance (pure arithmetic on the gathered times): widths stay multiples of the 8-column tile, every rank keeps at
+    least one tile, the slow rank's slab shrinks and the fast one's grows, equal times leave equal widths alone, and the same inputs give the
+    same edges (every rank runs this on the same gathered numbers)."""
+    from lidar_rt_amd.parallel import ShardedTracer, column_slab
+
+    def balancer(world, W):
+        b = ShardedTracer.__new__(ShardedTracer); b.world = world; b.rank = 0
+        b._edges = [column_slab(W, r, world)[0] for r in range(world)] + [W]; b._edges_key = (W, world); b._times = None
+        return b
+
+    W = 2048
+    b = balancer(4, W); b._times = [1.0, 1.0, 1.0, 1.0]; b._rebalance(W)
+    assert b._edges == [0, 512, 1024, 1536, 2048]
+    b._times = [2.0, 1.0, 1.0, 1.0]; b._rebalance(W)
+    w = [b._edges[i + 1] - b._edges[i] for i in range(4)]
+    assert w[0] < 512 and all(x > 512 for x in w[1:]) and sum(w) == W and all(x % 8 == 0 for x in w)
+    b2 = balancer(4, W); b2._times = [1.0, 1.0, 1.0, 1.0]; b2._rebalance(W); b2._times = [2.0, 1.0, 1.0, 1.0]; b2._rebalance(W)
+    assert b2._edges == b._edges                                               # deterministic
+    for _ in range(40):                                                         # a rank that stays 50x slower is squeezed, never below one tile
+        b._times = [50.0, 1.0, 1.0, 1.0]; b._rebalance(W)
+    w = [b._edges[i + 1] - b._edges[i] for i in range(4)]
+    assert w[0] >= 8 and min(w) >= 8 and sum(w) == W and all(x % 8 == 0 for x in w)
+    b = balancer(8, 2650)                                                       # a width that is not a multiple of 8 x ranks (configs[4])
+    b._times = [1.0, 1.2, 1.3, 1.1, 0.9, 1.6, 1.4, 1.1]; b._rebalance(2650)
+    e = b._edges
+    assert e[0] == 0 and e[-1] == 2650 and all(e[i + 1] > e[i] for i in range(8)) and all(x % 8 == 0 for x in e[1:-1])
+    b._times = [1.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]; before = list(b._edges); b._rebalance(2650)
+    assert b._edges == before                                                   # a missing time (0) changes nothing
