@@ -308,6 +308,8 @@ class ShardedTracer:
         t = self._times
         if not t or len(t) != self.world or min(t) <= 0.0:
             return
+        if max(t) * len(t) < 1.05 * sum(t):                    # within 5 % of the mean: leave the edges alone (every move costs the ranks whose
+            return                                             # slab changes a culled build whose size has to be found again)
         if self._edges is None or self._edges_key != (W, self.world):
             self._edges = [column_slab(W, r, self.world)[0] for r in range(self.world)] + [W]; self._edges_key = (W, self.world)
         w = [self._edges[r + 1] - self._edges[r] for r in range(self.world)]
@@ -344,6 +346,16 @@ class ShardedTracer:
                 while len(self._cull_counts) > 16384:
                     self._cull_counts.popitem(last=False)
         g = self._cull_counts.get(key)
+        if g is None:
+            # the same rays and P with other slab edges (the balancer moved them by a few tiles): the kept count scales about like the width
+            if isinstance(key, tuple) and len(key) == 4:
+                ident, a, b, P_ = key
+                for seen, (k2, n2) in enumerate(reversed(self._cull_counts.items())):
+                    if seen >= 256:
+                        break
+                    if isinstance(k2, tuple) and len(k2) == 4 and k2[0] == ident and k2[3] == P_ and \
+                            min(b, k2[2]) - max(a, k2[1]) >= 0.75 * max(b - a, k2[2] - k2[1]):
+                        g = int(n2 * (b - a) / max(k2[2] - k2[1], 1) * 1.15); break
         st.set_option("cull_next", 0 if g is None else g + g // 4 + 4096)
         self._cull_prev_key = key
         self.cull_readbacks += 1 if g is None else 0

@@ -173,3 +173,28 @@ def test_slab_balancer_moves_edges_towards_equal_time_and_keeps_the_tiling():
     assert e[0] == 0 and e[-1] == 2650 and all(e[i + 1] > e[i] for i in range(8)) and all(x % 8 == 0 for x in e[1:-1])
     b._times = [1.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]; before = list(b._edges); b._rebalance(2650)
     assert b._edges == before                                                   # a missing time (0) changes nothing
+
+
+def test_a_moved_slab_edge_does_not_cost_a_read_back():
+    """After the balancer has moved a rank's edges by a few tiles the culled build of the new slab is sized from the old slab's count scaled
+    by the width (x 1.15, then the usual x 1.25 + 4096) -- no host wait; a slab that overlaps less than 75 % is unknown."""
+    import torch
+    from lidar_rt_amd.parallel import ShardedTracer
+
+    class State:
+        def __init__(self): self.last, self.next = -1, None
+        def get_option(self, name, dev=None): return self.last
+        def set_option(self, name, v): self.next = v
+
+    class Backend:
+        def __init__(self): self.state = State()
+
+    tr = ShardedTracer(backend=Backend()); tr._dev = torch.device("cpu"); st = tr.backend.state
+    tr._cull_sizing(("rays", 256, 512, 1000)); assert st.next == 0
+    st.last = 100_000
+    tr._cull_sizing(("rays", 248, 520, 1000))                                   # 272 columns instead of 256, same rays and P
+    g = int(100_000 * 272 / 256 * 1.15); assert st.next == g + g // 4 + 4096 and tr.cull_readbacks == 1
+    st.last = 107_000
+    tr._cull_sizing(("rays", 1024, 1280, 1000)); assert st.next == 0 and tr.cull_readbacks == 2      # another sector: unknown
+    tr._cull_sizing(("rays", 256, 512, 1001)); assert st.next == 0                                   # another P: unknown
+    tr._cull_sizing(("other", 256, 512, 1000)); assert st.next == 0                                  # other rays: unknown
