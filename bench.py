@@ -112,6 +112,35 @@ def _cpu_model():
     return "unknown"
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks here -- the command the driver would
+    have used (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), one device per rank -- instead
+    of silently measuring one rank.  Refuses (exit code 2) when the node has fewer than N devices (LRT_SINGLE_DEVICE=1, the developer
+    switch that stacks all ranks on cuda:0, lifts that)."""
+    n = int(args.gpus)
+    single = os.environ.get("LRT_SINGLE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--print-launch"]
+    if args.print_launch:
+        print(json.dumps({"launch": cmd, "devices_visible": have, "single_device": single}), flush=True)
+        return 0
+    if have < (1 if single else n):
+        print(f"[bench] refusing: --gpus {n} needs {n} visible HIP devices, this node shows {have} "
+              "(no CPU fallback; LRT_SINGLE_DEVICE=1 LRT_DIST_BACKEND=gloo stacks the ranks on one device for development)", file=sys.stderr)
+        return 2
+    import subprocess
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,8 +155,9 @@ def main():
                     "training step -- consumes; nothing else has to be synchronised); dense = all_reduce of the flat buffer (replicated); owner = "
                     "every Gaussian's gradient is reduced to its owning rank only (reduce-scatter semantics: NOT a complete training exchange, "
                     "parameters and Adam moments of the touched rows would still have to be synchronised)")
-    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed window is repeated in whole blocks of --steps until it lasts "
-                    "at least this long (one window, bracketed once; `steps` in the output is what ran, `steps_requested` what was asked); 0 = exactly --steps")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="length of the SUSTAINED window that runs in front of the timed one (whole blocks of --steps until it "
+                    "lasts at least this long; clocks and caches are warm afterwards, and driver-side telemetry sees the GPU busy).  It is reported as `sustained` "
+                    "BESIDE `value`; `value` itself always comes from EXACTLY --steps steps, bracketed by barrier + synchronize.  0 = no sustained window")
     ap.add_argument("--check-sum", action="store_true", help="add checksums of the (all-gathered / all-reduced) results")
     ap.add_argument("--via", default="direct", choices=["direct", "tracer"], help="direct (default): the step drives the `_C` binding through ShardedTracer "
                     "with preallocated gradient views; tracer: the DROP-IN path a maintainer gets -- diff_lidar_tracer.Tracer -> torch.autograd -> `_C` "
@@ -136,7 +166,11 @@ def main():
     ap.add_argument("--both-paths", dest="both_paths", action="store_true", default=True,
                     help="(default on one GPU) time the other --via path too, same window length, and report it beside `value` as `drop_in_path` / `direct_path`")
     ap.add_argument("--no-both-paths", dest="both_paths", action="store_false", help="time only the --via path")
-    ap.add_argument("--vary", action="store_true", help="add a second timed window in which the frame CHANGES from step to step like in training "
+    ap.add_argument("--no-vary", dest="vary", action="store_false", help="skip the `value_varying` window")
+    ap.add_argument("--pose-inside", action="store_true", help="--vary poses 0.1 m from clutter instead of inside the scene's empty cylinder: hundreds of rays start closer than "
+                    "0.2 m to a quad and take the literal K-buffer replay (k_fwd_near); reported as `value_varying.near_rays_per_frame` / `near_us`")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no torch.distributed environment: print the launch command as JSON and exit (tests)")
+    ap.add_argument("--vary", action="store_true", default=True, help="(default on one GPU) a second timed window in which the frame CHANGES from step to step like in training "
                     "(train.py:125-148 draws another frame per iteration and the optimizer moves the parameters): 4 sensor poses (yawed / translated ray sets) "
                     "in rotation and an Adam-sized perturbation of means / scales / opacities between steps.  Reported as `value_varying` BESIDE `value`: "
                     "it shows what the temporal speculation (per-tile learned slab widths, Morton box of the previous build, speculated hit counts) is worth "
@@ -152,14 +186,23 @@ def main():
                     "configuration: the reference rebuilds its acceleration structure on every call, and so does the default step)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))                      # re-enters this file once per rank under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] refusing: --gpus {args.gpus} but torch.distributed started WORLD_SIZE={world} ranks; the line would report "
+                  f"{world} rank(s) as {args.gpus}", file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
     # developer switches to exercise the N>1 path on a 1-GPU box: all ranks on cuda:0, gloo instead of RCCL
     single_dev = os.environ.get("LRT_SINGLE_DEVICE", "0") == "1"
     backend = os.environ.get("LRT_DIST_BACKEND", "nccl")
+    if world > 1 and not single_dev and torch.cuda.device_count() < world:
+        raise SystemExit(f"[bench] refusing: {world} ranks but {torch.cuda.device_count()} visible devices (one device per rank)")
     dev_index = 0 if single_dev else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -169,8 +212,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     # ---------------- synthetic workload (identical on every rank: seeded)
     if args.workload == "s1m":
@@ -243,9 +284,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # how many blocks of --steps make the timed window at least --min-seconds long (so that driver-side telemetry can see the GPU
-    # busy): one calibration block, then ONE timed window of `reps` blocks; every rank uses the same count
-    reps = 1
+    # ---- the SUSTAINED window first: whole blocks of --steps until it lasts --min-seconds (one calibration block sizes it; every rank uses
+    # the same count).  It is reported beside `value` and leaves clocks / caches / the library's speculation warm for the timed window.
+    st.set_option("timing_every", max(1, args.time_every))
+    reps, sustained = 0, None
     if args.min_seconds > 0 and args.steps > 0:
         barrier(); tc = time.perf_counter()
         for _ in range(args.steps):
@@ -254,10 +296,22 @@ def main():
         reps = max(1, int(np.ceil(args.min_seconds / max(cal, 1e-6))))
         if world > 1:
             tr_ = torch.tensor([reps], dtype=torch.int64, device=dev); dist.all_reduce(tr_, op=dist.ReduceOp.MAX); reps = int(tr_.item())
-    steps_run = args.steps * reps
-    # the library's region timers (HIP events on the launch stream around build / forward / colour pass / backward) run INSIDE the timed window,
-    # on every 8th step: an event record between two kernels costs ~5 us of pipeline, eight per step were 3-5 % of the step they measure
-    st.set_option("timing_every", max(1, args.time_every))
+        st.enable_timing(not args.graph)
+        barrier(); ts0 = time.perf_counter()
+        for _ in range(args.steps * reps):
+            step()
+        barrier(); el_s = time.perf_counter() - ts0
+        if world > 1:
+            te = torch.tensor([el_s], dtype=torch.float64, device=dev); dist.all_reduce(te, op=dist.ReduceOp.MAX); el_s = float(te.item())
+        kts = st.get_timing(dev); st.enable_timing(False)
+        sustained = {"value": H * W * args.steps * reps / el_s, "unit": "rays/s", "steps": args.steps * reps, "seconds": el_s,
+                     "ms_per_step": 1e3 * el_s / (args.steps * reps),
+                     "phase_ms": {k_: kts[k_][0] / max(kts[k_][1], 1) for k_ in ("build", "fwd", "bwd")}}
+    steps_long = args.steps * max(reps, 1)                            # length of the other secondary windows (drop-in path, varying frame)
+    # ---- the timed window: EXACTLY --steps steps, barrier + synchronize on both sides, max over ranks.
+    # The library's region timers (HIP events on the launch stream around build / forward / colour pass / backward) run INSIDE it, on every
+    # --time-every-th step: an event record between two kernels costs ~5 us of pipeline, eight per step were 3-5 % of the step they measure
+    steps_run = args.steps
     st.enable_timing(not args.graph)                                  # (they record events between kernels: not inside a graph)
     tr.enable_phase_timing(True, every=max(1, args.time_every))
     barrier()
@@ -274,6 +328,35 @@ def main():
     st.enable_timing(False)
     phases = tr.phase_timing()
     tr.enable_phase_timing(False)
+    if sustained is not None and any(kt[k_][1] == 0 for k_ in ("build", "fwd", "bwd")):
+        kt = kts                                                      # a window shorter than --time-every steps holds no sample: the sustained window's averages
+
+    # ---- N > 1: every rank's own compute (its library regions: build + forward + backward), and the unsharded step of the same workload on rank 0
+    per_rank_ms, value_n1 = None, None
+    if world > 1:
+        mine = torch.tensor([kt[k_][0] / max(kt[k_][1], 1) for k_ in ("build", "fwd", "bwd")], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [{"build": float(a_[0]), "forward": float(a_[1]), "backward": float(a_[2]), "sum": float(a_.sum())} for a_ in allr]
+        if rank == 0:
+            tr1 = ShardedTracer(exchange=args.exchange, world=1, rank=0)
+            for kv in args.opt:
+                k_, v_ = kv.split("="); tr1.backend.state.set_option(k_, int(v_))
+            def step1():
+                tr1.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step)
+                tr1.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
+            if args.no_build_in_step:
+                tr1.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+            for _ in range(max(args.warmup, 3)):
+                step1()
+            torch.cuda.synchronize(); t1_ = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            torch.cuda.synchronize(); e1_ = time.perf_counter() - t1_
+            value_n1 = {"value": H * W * args.steps / e1_, "unit": "rays/s", "steps": args.steps, "ms_per_step": 1e3 * e1_ / args.steps,
+                        "note": "the unsharded step of the same workload on rank 0's device, timed right behind the sharded window while the other ranks wait"}
+            del tr1
+        barrier()
 
     other = None
     if args.both_paths and world == 1:
@@ -281,9 +364,9 @@ def main():
         for _ in range(max(args.warmup, 1)):
             ostep()
         barrier(); t1 = time.perf_counter()
-        for _ in range(steps_run):
+        for _ in range(steps_long):
             ostep()
-        barrier(); other = H * W * steps_run / (time.perf_counter() - t1)
+        barrier(); other = H * W * steps_long / (time.perf_counter() - t1)
 
     # ---------------- the same step on a frame that changes every iteration (--vary)
     varying = None
@@ -292,6 +375,16 @@ def main():
         # the sensor stays inside the scene's empty cylinder (r < 2 m around the origin): a pose inside the clutter would make hundreds of
         # "near rays" (a quad closer than 0.2 m: the literal K-buffer replay of lrt_near.inc), which is a property of that pose, not of a moving frame
         yaws = [0.0, 0.35, -0.6, 1.3]; shifts = [(0.0, 0.0, 0.0), (0.30, -0.20, 0.05), (-0.35, 0.25, -0.03), (0.15, 0.40, 0.02)]
+        if args.pose_inside:
+            # --pose-inside: the sensor 0.1 m from a clutter Gaussian's centre, along its normal (train.py's real sensors sit inside geometry): the rays
+            # that start closer than 0.2 m to a quad are the literal K-buffer replay's (k_fwd_near) -- the case the default poses avoid
+            m_ = sc["means"]; r_ = np.hypot(m_[:, 0], m_[:, 1])
+            cand = np.nonzero((r_ > 5.0) & (r_ < 40.0) & (m_[:, 2] > 0.0) & (m_[:, 2] < 2.0))[0]
+            pick = cand[np.linspace(0, len(cand) - 1, n_pose).astype(int)]
+            q_ = sc["rotations"][pick]; q_ = q_ / np.linalg.norm(q_, axis=1, keepdims=True)
+            nrm = np.stack([2 * (q_[:, 1] * q_[:, 3] + q_[:, 0] * q_[:, 2]), 2 * (q_[:, 2] * q_[:, 3] - q_[:, 0] * q_[:, 1]),
+                            1 - 2 * (q_[:, 1] ** 2 + q_[:, 2] ** 2)], 1)
+            shifts = [tuple(float(x) for x in (m_[i_] + 0.1 * n_)) for i_, n_ in zip(pick, nrm)]
         poses = []
         for yw, sh in zip(yaws, shifts):
             c_, s_ = float(np.cos(yw)), float(np.sin(yw))
@@ -317,15 +410,21 @@ def main():
             step_vary(i)
         st.enable_timing(True)
         barrier(); tv = time.perf_counter()
-        for i in range(steps_run):
+        for i in range(steps_long):
             step_vary(i)
         barrier(); el_v = time.perf_counter() - tv
         ktv = st.get_timing(dev); st.enable_timing(False)
         st.check(dev, wait=True)                                                      # an overflow of a speculated capacity would surface here
+        near = None
+        if args.pose_inside:
+            near = []
+            for i in range(n_pose):
+                step_vary(i); torch.cuda.synchronize()
+                near.append(int(st.get_option("near_rays_last", dev)))
         for k, v in saved.items():
             t[k].copy_(v)
-        varying = {"value": H * W * steps_run / el_v, "unit": "rays/s", "steps": steps_run, "ms_per_step": 1e3 * el_v / steps_run,
-                   "poses": n_pose, "yaw_rad": yaws, "shift_m": shifts,
+        varying = {"value": H * W * steps_long / el_v, "unit": "rays/s", "steps": steps_long, "ms_per_step": 1e3 * el_v / steps_long,
+                   "poses": n_pose, "yaw_rad": yaws, "shift_m": shifts, "pose_inside": bool(args.pose_inside), "near_rays_per_frame": near,
                    "phase_ms": {k_: ktv[k_][0] / max(ktv[k_][1], 1) for k_ in ("build", "fwd", "bwd")},
                    "parameter_step": "means += N(0, 1e-3 m), scales *= 1 + N(0, 5e-3), opacities += N(0, 0.01) per step (signs alternate); the three "
                                      "in-place updates (~10 us of elementwise kernels) are inside the timed window"}
@@ -364,8 +463,9 @@ def main():
             C, K = gs["C_mean_candidates_per_ray"], gs["K_mean_composited_per_ray"]
             ck_src = "oracle (tests/golden/s1m_stats.json)"
         else:
-            C = hs.get("candidates", 0) / 2.0 / max(rays_local, 1); K = hs.get("composited", 0) / 2.0 / max(rays_local, 1)
-            ck_src = "HIP counters of this run"
+            # the bucketed backward replays the hit record: nothing is counted twice (S1M: composited = 3,939,575 = 30.06 x 131,072 exactly)
+            C = hs.get("candidates", 0) / max(rays_local, 1); K = hs.get("composited", 0) / max(rays_local, 1)
+            ck_src = "HIP counters of this run (forward traversal of the instrumented step)"
         bf, bb = algorithmic_bytes(C, K, deg)
         ms_f = kt["fwd"][0] / max(kt["fwd"][1], 1); ms_b = kt["bwd"][0] / max(kt["bwd"][1], 1)
         ms_build = kt["build"][0] / max(kt["build"][1], 1)
@@ -385,6 +485,9 @@ def main():
         per_kernel = {k: {"algorithmic_bytes": alg[k], "live_ms": live_ms[k],
                           "frac_algorithmic": (alg[k] / (live_ms[k] * 1e-3) / HBM_PEAK_BYTES_PER_S) if live_ms[k] > 0 else None} for k in alg}
         per_kernel["k_fwd_cr4"]["live_ms_note"] = "forward region minus the colour pass (includes k_fwd_near, a few us)"
+        # the SURVEY 8(d) backward term prices 58 read-modify-write atomics per hit (backward.cu:615,659-669) that the replay design never
+        # performs (one row store per touched Gaussian): its "fraction" is a model figure, NOT traffic -- the counter fraction is beside it
+        per_kernel["backward"]["model_fraction_not_traffic"] = per_kernel["backward"].pop("frac_algorithmic")
         tp = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
@@ -417,6 +520,9 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json unreadable: {ex}"
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_BYTES_PER_S / 1e9), "traffic": traffic,
+                # the companion of `frac`: counter-measured HBM bytes of the same region (committed rocprofv3 PMC profile of the same sources) over
+                # this run's live time of that region
+                "frac_counters": (traffic / (dom_ms * 1e-3) / HBM_PEAK_BYTES_PER_S) if (traffic and dom_ms > 0) else None,
                 # `traffic` = counter bytes per step of the dominant region's kernels with the guide's gfx950 correction (2 x FETCH_SIZE +
                 # WRITE_SIZE); the uncorrected sum beside it; which applies to which access pattern: profiles/r04_fetch_calibration.md
                 "traffic_uncorrected": traffic_raw,
@@ -440,6 +546,8 @@ def main():
             "metric": "LiDAR rays/s fwd+bwd @1M Gaussians, 2048x64 sweep; % HBM roofline",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": steps_run, "steps_requested": args.steps, "warmup": args.warmup,
             "timed_window_s": elapsed,
+            # the same step over a window of --min-seconds, run in front of the timed one
+            "sustained": sustained,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
@@ -455,8 +563,13 @@ def main():
             "phase_ms": {"build": ms_build, "forward": ms_f, "backward": ms_b, **{k: v for k, v in phases.items()}},
             "hip_counters_per_step": {k: v for k, v in hs.items()},
         }
+        if world > 1:
+            res["value_n1"] = value_n1
+            res["per_rank_compute_ms"] = per_rank_ms
+            res["exchange_ms"] = {"slab_all_gather": phases.get("slab_all_gather"), "gradient_exchange": phases.get("gradient_exchange")}
+            res["speedup_vs_n1"] = (value / value_n1["value"]) if value_n1 else None
         if other is not None:
-            res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_run}
+            res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_long}
         if varying is not None:
             res["value_varying"] = varying
         if args.check_sum:

@@ -902,6 +902,13 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
         *value = st->cone_seen ? (int)st->cone_prev : -1;
         return LRT_OK;
     }
+    if (!strcmp(name, "near_rays_last")) {                   // rays the last collect & resolve forward handed to k_fwd_near (a quad closer than 0.2 m); waits for the device
+        DeviceGuard dg(st->device);
+        unsigned n = 0u;
+        if (st->ctrl) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(&n, st->ctrl + 13, sizeof(n), hipMemcpyDeviceToHost)); }
+        *value = (int)n;
+        return LRT_OK;
+    }
     LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: unknown option '%s'", name);
 }
 

@@ -130,10 +130,12 @@ _TAKES_CACHE: Dict[tuple, bool] = {}
 class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
-    def __init__(self, backend=None, group=None, exchange: str = "sparse"):
+    def __init__(self, backend=None, group=None, exchange: str = "sparse", world: Optional[int] = None, rank: Optional[int] = None):
         """exchange: "owner" = rows of touched Gaussians go to their owning rank (complete gradient on the owner only); "dense" = one
         all_reduce of the flat gradient buffer (replicated); "sparse" = all_gather of the touched rows (replicated); "auto" = sparse
-        unless the ranks together touched more than `sparse_max_fraction` of the Gaussians, then dense."""
+        unless the ranks together touched more than `sparse_max_fraction` of the Gaussians, then dense.
+        world / rank: override what `torch.distributed` reports -- world=1 makes a plain single-rank tracer inside a multi-rank job
+        (bench.py's `value_n1`: rank 0 times the unsharded step of the same workload beside the sharded one)."""
         if exchange not in ("auto", "dense", "sparse", "owner"):
             raise ValueError("exchange must be 'auto', 'dense', 'sparse' or 'owner'")
         self.exchange = exchange
@@ -142,8 +144,8 @@ class ShardedTracer:
         self.last_owner: Optional[torch.Tensor] = None  # (P,) int32 owner map of the last "owner" exchange
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = int(rank) if rank is not None else (dist.get_rank(group) if (dist.is_initialized() and world is None) else 0)
         # build the LBVH for this rank's rays only (lrt_build_for_rays): Gaussians outside the cone around the slab's rays are left
         # out.  The library sizes the sort and the tree from the previous frame's kept count, so no read-back stalls the launch
         # queue.  Measured on S1M (tools/slab_timing.py, CULL=1, profiles/r03_summary.md): with the division-free cone test of round 3

@@ -40,9 +40,11 @@ for name, k in (("clk_us", None), ("slabs", 1), ("nodes", 2), ("prim_rounds", 3)
 if os.environ.get("C4_PROF"):
     raw = np.empty(16384 * 64, np.float32)
     be.state._lib.lrt_debug_read(h, 4, raw.ctypes.data_as(C.c_void_p), raw.nbytes, None)
-    pr = raw[8 * NT: 8 * NT + 16 * NT].reshape(NT, 16)[:, :10]
+    pr = raw[8 * NT: 8 * NT + 16 * NT].reshape(NT, 16)
     names = ["first select+commit", "select_issue(next)", "process leaves", "process nodes", "round barrier", "push counters + late select", "commit (vmcnt wait + LDS stores)",
-             "phase A tail (waitcnt, barrier, overflow test)", "slab prologue (barriers, flags)", "phase B"]
+             "phase A tail (waitcnt, barrier, overflow test)", "slab prologue (barriers, flags)", "phase B: prologue, per-ray sums + state write, tail",
+             "phase B: list loads waited for, exp, stage t in LDS", "phase B: rank pass", "phase B: rank check + scatter by rank", "phase B: ray state, tie refine, chunk rule",
+             "phase B: alpha, prefix product, stop test", "phase B: composite (weights, accum atomics, hit record)"]
     tot = pr.sum()
     print("wave-0 cycles per tile by segment (mean; share):")
     for k, n in enumerate(names):
