@@ -89,6 +89,12 @@ def build_ext(force: bool = False, verbose: bool = False) -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     lib = _build_lib(force, verbose)
+    # the resource gate (lidar_rt_amd/resources.py): no instantiation of k_fwd_cr4 may spill a vector register or use scratch.  Checked on
+    # every call, also for a library that was not recompiled: the .so that ships is the one that must pass
+    from . import resources
+    res = resources.check(lib)
+    if verbose:
+        print(resources.table_md(res, r"^k_fwd_cr4<"), flush=True)
     build_ext(force, verbose)
     return lib
 

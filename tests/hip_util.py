@@ -62,6 +62,13 @@ def frac_outside(a, b, rtol, floor=1e-3):
 FLOOR_K = 2.5            # on the fraction of elements beyond the tolerance (a count of events: robust)
 FLOOR_K_L2 = 4.0         # on the relative L2 error (dominated by the one or two largest events of an image: heavy-tailed)
 OUT_TOL, GRAD_TOL = 1e-4, 1e-3            # BASELINE.json north_star: 1e-4 relative on rendered channels, 1e-3 on gradients
+# Round 5: the PRIMARY gate is arbitrated by the fp64 oracle -- "the HIP path is no farther from the exact answer than
+# the reference's own fp32 arithmetic": for every channel and every gradient, HIP-vs-fp64 must stay within F64_K x the fp32-oracle-vs-fp64
+# statistic (the floor).  The fraction of elements beyond the tolerance is a count of events and gets a 3-sigma counting allowance
+# (both counts are Poisson-like: sqrt(n_floor) events); the relative L2 error is dominated by the one or two largest events of an image
+# (heavy-tailed), so its factor is looser.  (1.1, 1.25) is the claim itself; scenes on which the measurement does not support it pass their
+# own, larger factors and say so (tests/test_hip_parity.py, tests/test_config_shapes_gpu.py; measured ratios: BASELINE.md section 6).
+F64_K = (1.1, 1.25)
 
 
 def parity_stats(got, ref, rtol, floor=1e-3):
@@ -79,7 +86,7 @@ def parity_stats(got, ref, rtol, floor=1e-3):
 OUT_CHANNELS = ((0, "intensity"), (1, "rayhit"), (2, "raydrop"), (3, "depth"), (4, "weight"), (8, "transmittance"))
 
 
-def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations", "opacities", "shs"), extra=None, k=FLOOR_K, check=True):
+def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations", "opacities", "shs"), extra=None, k=FLOOR_K, check=True, f64_k=F64_K):
     """Compare hip = {"out", "accum", "grads": {...}} with the fp32 oracle results f32 = (fw, bw) and, when the fp64 oracle
     results are given, assert every statistic within k x the f32-vs-f64 floor (or within the north-star tolerance itself where
     the floor is below it).  Writes the table to gpurun_out/parity/<name>.json and returns it."""
@@ -102,7 +109,13 @@ def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations
     if bw is not None and "grads" in hip:
         for g in grads:
             add(f"grad.{g}", hip["grads"][g].reshape(bw[g].shape), bw[g], GRAD_TOL, None if f64 is None else f64[1][g])
-    rep = {"name": name, "k_frac": k, "k_l2": k * (FLOOR_K_L2 / FLOOR_K), "asserted": bool(check), "rows": rows, **(extra or {})}
+    rep = {"name": name, "k_frac": k, "k_l2": k * (FLOOR_K_L2 / FLOOR_K), "f64_k_frac": f64_k[0] if f64_k else None, "f64_k_l2": f64_k[1] if f64_k else None,
+           "asserted": bool(check), "rows": rows, **(extra or {})}
+    # ratios of the fp64-arbitrated gate, for the record (worst row of each statistic)
+    if f64 is not None:
+        rf = [(st["vs_f64"]["frac_gt_tol"] * st["n"] + 1.0) / (st["floor"]["frac_gt_tol"] * st["n"] + 1.0) for st in rows.values() if "vs_f64" in st]
+        rl = [st["vs_f64"]["rel_l2"] / max(st["floor"]["rel_l2"], 1e-30) for st in rows.values() if "vs_f64" in st and st["floor"]["rel_l2"] > st["tol"] * 1e-2]
+        rep["f64_gate_worst"] = {"frac_ratio": max(rf) if rf else None, "l2_ratio": max(rl) if rl else None}
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity")
         os.makedirs(d, exist_ok=True)
@@ -122,4 +135,19 @@ def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations
         if st["rel_l2"] > max(k * (FLOOR_K_L2 / FLOOR_K) * st["floor"]["rel_l2"], 2 * tol):
             bad.append((label, "rel_l2", st["rel_l2"], st["floor"]["rel_l2"]))
     assert not (check and bad), f"{name}: beyond {k} x the f32-vs-f64 floor: {bad}"
+    # ---- the fp64-arbitrated gate: HIP against the fp64 oracle, bounded by the fp32 oracle against the fp64 oracle
+    bad64 = []
+    if f64_k:
+        for label, st in rows.items():
+            if "vs_f64" not in st:
+                continue
+            tol, n = st["tol"], max(st["n"], 1)
+            ev_floor = st["floor"]["frac_gt_tol"] * n
+            allow = (f64_k[0] * ev_floor + 3.0 * np.sqrt(ev_floor + 1.0)) / n
+            if st["vs_f64"]["frac_gt_tol"] > max(allow, 1e-3 if tol == OUT_TOL else 2e-3):
+                bad64.append((label, "frac_gt_tol", st["vs_f64"]["frac_gt_tol"], st["floor"]["frac_gt_tol"]))
+            if st["vs_f64"]["rel_l2"] > max(f64_k[1] * st["floor"]["rel_l2"], 2 * tol):
+                bad64.append((label, "rel_l2", st["vs_f64"]["rel_l2"], st["floor"]["rel_l2"]))
+    assert not (check and bad64), (f"{name}: the HIP path is farther from the fp64 oracle than {f64_k} x the fp32 oracle is "
+                                   f"(label, statistic, HIP-vs-f64, f32-vs-f64): {bad64}")
     return rep

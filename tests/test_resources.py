@@ -1,0 +1,51 @@
+"""The shipped library's kernels against the build-time resource gate (lidar_rt_amd/resources.py): no GPU needed,
+the numbers are read from the code objects' metadata notes."""
+import os
+import re
+
+import pytest
+
+from lidar_rt_amd import build as lrt_build
+from lidar_rt_amd import resources
+
+
+@pytest.fixture(scope="module")
+def table():
+    if not os.path.exists(lrt_build.LIB):
+        lrt_build.build()
+    return resources.kernel_resources(lrt_build.LIB)
+
+
+def test_every_cr4_instantiation_is_free_of_vector_spills_and_scratch(table):
+    cr4 = {n: r for n, r in table.items() if re.search(r"^k_fwd_cr4<", n)}
+    # DEFER_COLOUR x waves per tile {4, 8} x STATS: all eight are shipped (options fwd_mode / defer_colour / c4_waves / the counters)
+    assert len(cr4) == 8, sorted(cr4)
+    assert resources.violations(table) == []
+    for n, r in cr4.items():
+        assert r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0 and not r["dynamic_stack"], (n, r)
+    # the production launches are held at 128 registers = 4 workgroups of 4 waves (2 of 8) per CU, and their LDS allows that
+    for n in ("k_fwd_cr4<true, 4, false>", "k_fwd_cr4<true, 8, false>"):
+        assert cr4[n]["vgpr"] + cr4[n]["agpr"] <= 128, (n, cr4[n])
+    assert cr4["k_fwd_cr4<true, 4, false>"]["workgroups_per_cu"] == 4
+    assert cr4["k_fwd_cr4<true, 8, false>"]["workgroups_per_cu"] == 2
+
+
+def test_gate_fails_on_a_spilling_kernel(table):
+    fake = dict(table)
+    fake["k_fwd_cr4<true, 16, false>"] = {**table["k_fwd_cr4<true, 4, false>"], "vgpr_spill": 15, "scratch_bytes": 64}
+    bad = resources.violations(fake)
+    assert len(bad) == 1 and "k_fwd_cr4<true, 16, false>" in bad[0]
+    # kernels outside the gate may use scratch (k_trace's K-buffer does) without failing it
+    assert resources.violations({"k_other": {**table["k_fwd_cr4<true, 4, false>"], "vgpr_spill": 3, "scratch_bytes": 12}}) == []
+
+
+def test_committed_table_matches_the_library(table):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_resources.md")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r05_resources.md not written yet")
+    txt = open(path).read()
+    if f"kernel sources `{lrt_build.source_hash()}`" not in txt:
+        pytest.skip("profiles/r05_resources.md was written for other kernel sources")
+    for n in ("k_fwd_cr4<true, 4, false>", "k_fwd_cr4<true, 8, false>"):
+        r = table[n]
+        assert f"| `{n}` | {r['vgpr']} | {r['agpr']} | {r['sgpr']} | 0 |" in txt
