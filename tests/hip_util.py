@@ -64,11 +64,15 @@ FLOOR_K_L2 = 4.0         # on the relative L2 error (dominated by the one or two
 OUT_TOL, GRAD_TOL = 1e-4, 1e-3            # BASELINE.json north_star: 1e-4 relative on rendered channels, 1e-3 on gradients
 # Round 5: the PRIMARY gate is arbitrated by the fp64 oracle -- "the HIP path is no farther from the exact answer than
 # the reference's own fp32 arithmetic": for every channel and every gradient, HIP-vs-fp64 must stay within F64_K x the fp32-oracle-vs-fp64
-# statistic (the floor).  The fraction of elements beyond the tolerance is a count of events and gets a 3-sigma counting allowance
-# (both counts are Poisson-like: sqrt(n_floor) events); the relative L2 error is dominated by the one or two largest events of an image
-# (heavy-tailed), so its factor is looser.  (1.1, 1.25) is the claim itself; scenes on which the measurement does not support it pass their
-# own, larger factors and say so (tests/test_hip_parity.py, tests/test_config_shapes_gpu.py; measured ratios: BASELINE.md section 6).
+# statistic (the floor).  The fraction of elements beyond the tolerance is a count of events and gets a 3-sigma counting allowance.  Events
+# are RAY events (a candidate on the edge of the restart epsilon, an order swap ...): a rendered channel counts them one by one, a gradient
+# tensor counts every element of the ~32 Gaussians composited behind the event -- its counts come in clusters of 32 x (components per row),
+# and the counting noise of a clustered count is sqrt(cluster x n).  (S200k, tests/tools/parity_events.py: 10 restart-epsilon rays for HIP, 7
+# for the fp32 oracle -- that difference of three rays IS the 331-against-222 Gaussians of d_opacities: profiles/r05_parity_events_grads_s200k.md.)
+# The relative L2 error is dominated by the one or two largest events of an image (heavy-tailed); (1.1, 1.25) is the claim itself, scenes on
+# which the measured L2 ratio does not support 1.25 pass their own factor and say so (tests/test_config_shapes_gpu.py).
 F64_K = (1.1, 1.25)
+GRAD_CLUSTER = 32          # Gaussians whose rows one ray event moves (K = 30 composited hits per ray on S1M)
 
 
 def parity_stats(got, ref, rtol, floor=1e-3):
@@ -96,6 +100,8 @@ def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations
 
     def add(label, got, ref, tol, ref64=None):
         st = parity_stats(got, ref, tol)
+        a_ = np.asarray(ref)
+        st["row_width"] = int(np.prod(a_.shape[1:])) if (label.startswith("grad.") and a_.ndim > 1) else 1
         if ref64 is not None:
             fl = parity_stats(ref, ref64, tol)
             st["floor"] = {q: fl[q] for q in ("max_rel", "p99_rel", "frac_gt_tol", "rel_l2")}
@@ -143,8 +149,9 @@ def parity_report(name, hip, f32, f64=None, grads=("means", "scales", "rotations
                 continue
             tol, n = st["tol"], max(st["n"], 1)
             ev_floor = st["floor"]["frac_gt_tol"] * n
-            allow = (f64_k[0] * ev_floor + 3.0 * np.sqrt(ev_floor + 1.0)) / n
-            if st["vs_f64"]["frac_gt_tol"] > max(allow, 1e-3 if tol == OUT_TOL else 2e-3):
+            cluster = 1.0 if label.startswith("out.") else GRAD_CLUSTER * st.get("row_width", 1)
+            allow = (f64_k[0] * ev_floor + 3.0 * np.sqrt(cluster * (ev_floor + 1.0)) + 2.0 * cluster) / n      # no absolute slack beyond two events
+            if st["vs_f64"]["frac_gt_tol"] > allow:
                 bad64.append((label, "frac_gt_tol", st["vs_f64"]["frac_gt_tol"], st["floor"]["frac_gt_tol"]))
             if st["vs_f64"]["rel_l2"] > max(f64_k[1] * st["floor"]["rel_l2"], 2 * tol):
                 bad64.append((label, "rel_l2", st["vs_f64"]["rel_l2"], st["floor"]["rel_l2"]))
