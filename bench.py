@@ -246,7 +246,7 @@ def main():
 
     def step_direct():
         out, _ = tr.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg,
-                            rebuild=not args.no_build_in_step)
+                            rebuild=not args.no_build_in_step, cull_key="bench-frame")     # the ray set's name: sizes a rank's culled build without a read-back
         g = tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
         return out, g
 
@@ -343,7 +343,7 @@ def main():
             for kv in args.opt:
                 k_, v_ = kv.split("="); tr1.backend.state.set_option(k_, int(v_))
             def step1():
-                tr1.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step)
+                tr1.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step, cull_key="bench-frame")
                 tr1.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
             if args.no_build_in_step:
                 tr1.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
@@ -403,7 +403,8 @@ def main():
             t["scales"].mul_(d_scale[k_] if sgn > 0 else 1.0 / d_scale[k_])
             t["opacities"].add_(d_opac[k_], alpha=sgn).clamp_(0.01, 0.99)
             o_, d_ = poses[i % n_pose]
-            out_, _ = tr.forward(o_, d_, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step)
+            out_, _ = tr.forward(o_, d_, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step,
+                                 cull_key=("bench-pose", i % n_pose))
             tr.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
 
         for i in range(8):

@@ -1522,6 +1522,9 @@ static int launch_trace(lrt_state* st, TraceParams& tp, bool bwd, hipStream_t st
     tp.stats = st->stats_enabled ? st->stats : nullptr;
     tp.nsh = (tp.deg + 1) * (tp.deg + 1);
     if (tp.n_tiles == 0) return LRT_OK;
+    // a fused build leaves the tree levels >= 4 to the next forward's prologue; a re-tracing backward behind lrt_build / lrt_refit with no
+    // forward in between (legal in the C ABI) would walk unwritten top-level nodes: finish them here
+    if (bwd) finish_tree_now(st, stream);
     if (bwd && st->bwdq_fresh) { tp.tile_counter = st->ctrl + 16; st->bwdq_fresh = 0; }       // zeroed by the forward's prologue, used once
     else { HIPCHK(lrt_memset_async(st->lrec, st->tile_counter, 0, 8 * sizeof(unsigned), stream)); if (bwd) HIPCHK(lrt_memset_async(st->lrec, st->ctrl + 24, 0, 2 * sizeof(unsigned), stream)); }
     int blocks = (tp.n_tiles + 3) / 4;

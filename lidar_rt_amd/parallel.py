@@ -185,6 +185,8 @@ class ShardedTracer:
         self._step_no = 0
         self._t_events, self._t_last_ms, self._times = None, 0.0, None
         self._cull_counts, self._cull_prev_key, self.cull_readbacks = collections.OrderedDict(), None, 0     # see _cull_sizing
+        self._cull_exact_next = False  # the next culled build reads its count back (after error 8, see _drain)
+        self._build_id = 0             # counts the builds of this tracer: a backward re-traces only in the structure its forward used (see backward)
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
     def enable_phase_timing(self, on: bool = True, every: int = 1):
@@ -227,9 +229,9 @@ class ShardedTracer:
         else:
             self._pending.append((what, dev_values.clone(), None))
 
-    def check(self, wait: bool = True):
-        """Raise on EVERY rank alike if any rank reported an overflow in a step whose status has arrived (wait=True: in all
-        earlier steps).  Called at the start of forward()."""
+    def _drain(self, wait: bool):
+        """Look at the status words whose copies have arrived (wait=True: all of them).  Returns the first problem as (what, per-rank words) or
+        None; list lengths and compute times are absorbed on the way.  Identical on every rank: all ranks saw the same gathered words."""
         still = []
         bad = None
         for what, host, ev in self._pending:
@@ -251,15 +253,42 @@ class ShardedTracer:
                 bad = (what, vals)
         self._pending = still
         if bad is not None:
-            from ._capi import LrtError
             if hasattr(self.backend, "clear_errors") and getattr(self, "_dev", None) is not None and self._dev.type == "cuda":
                 self.backend.clear_errors(self._dev)
+            if bad[0].startswith("forward") and any(int(v) & 8 for v in bad[1]):
+                # a speculatively sized culled build lost primitives: the count remembered for that ray set was wrong; the next culled build
+                # of this tracer reads its count back (exact size)
+                self._cull_exact_next = True
+                if self._cull_prev_key is not None:
+                    self._cull_counts.pop(self._cull_prev_key, None)
+        return bad
+
+    _STATUS_HELP = ("forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
+                    "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly); "
+                    "'exchange' word 1 = a rank touched more Gaussians than the speculated message capacity (1.5 x the recent maximum): "
+                    "that step's gradients are incomplete on every rank alike; the capacity has been raised")
+
+    def check(self, wait: bool = True):
+        """Raise on EVERY rank alike if any rank reported an overflow in a step whose status has arrived (wait=True: in all
+        earlier steps).  Called at the start of forward()."""
+        bad = self._drain(wait)
+        if bad is not None:
+            from ._capi import LrtError
             what, vals = bad
             raise LrtError(f"sharded tracer: a rank reported an overflow in an earlier step ({what}; per-rank words {vals}); that step's "
-                           "results are incomplete on it.  forward status bits: 1 = candidate list, 2 = BVH queue, 4 = colour overflow list, "
-                           "8 = the speculatively sized ray-culled build lost primitives (the next build is sized exactly); "
-                           "'exchange' word 1 = a rank touched more Gaussians than the speculated message capacity (1.5 x the recent maximum): "
-                           "that step's gradients are incomplete on every rank alike; the capacity has been raised")
+                           "results are incomplete on it.  " + self._STATUS_HELP)
+
+    def verify_step(self):
+        """The guard a training loop calls between ``loss.backward()`` and the optimizer step (train.py:215-220): WAIT for the status words of
+        the step just enqueued -- every rank's forward / build bits and the exchange's overflow flag -- and return the first problem as
+        ``(what, per-rank words)``, or None when the step's image and gradients are complete on every rank.  Nothing is raised and the report
+        is consumed: the next build / exchange of this tracer is sized exactly (count read-back, capacity from the true list lengths), so a
+        caller re-runs the step and calls verify_step() again; a second failure must raise BEFORE the parameters move (training_step does
+        both).  Same answer on every rank (all ranks saw the same gathered words), so the ranks stay in step.  A single rank has nothing
+        speculative to verify: None."""
+        if self.world == 1 and not self.force_collectives and not self._pending:
+            return None
+        return self._drain(True)
 
     def check_replicas(self, tensors, what: str = "parameters"):
         """The replicated training design has NO parameter synchronisation: every rank must draw the same random numbers
@@ -335,8 +364,10 @@ class ShardedTracer:
         random from a drive: the count of a sector can change several-fold from one pose to the next, a too small size loses primitives (a loud
         error, code 8, but the optimizer step has happened by then).  So the counts are remembered PER RAY SET: a set seen before is sized
         speculatively from its own last count (x 1.25 + 4096, no host wait), a new one reads its count back (one 8-byte copy: the host waits for
-        the build's first kernels once).  `key` identifies the ray set: the caller's cull_key (renderer: the frame index) or the identity of
-        the ray tensors, plus the slab and P."""
+        the build's first kernels once).  `key` identifies the ray set: the caller's cull_key (renderer: the frame index) plus the slab and P.
+        A ray set WITHOUT a cull_key has no identity (round 4 used the tensors' addresses: the caching allocator hands the same address to the
+        next frame's rays, so different ray sets collided on one key -- ADVICE r04): its count is read back on every build.  A loop over the
+        same rays (bench.py, tools/slab_timing.py) passes a cull_key."""
         st = getattr(self.backend, "state", None)
         if st is None or not hasattr(st, "get_option"):
             return
@@ -348,9 +379,11 @@ class ShardedTracer:
                 while len(self._cull_counts) > 16384:
                     self._cull_counts.popitem(last=False)
         g = self._cull_counts.get(key)
-        if g is None:
+        if self._cull_exact_next:                              # a speculative size just lost primitives: this build reads its count back
+            g, self._cull_exact_next = None, False
+        elif g is None:
             # the same rays and P with other slab edges (the balancer moved them by a few tiles): the kept count scales about like the width
-            if isinstance(key, tuple) and len(key) == 4:
+            if isinstance(key, tuple) and len(key) == 4 and key[0] is not None:
                 ident, a, b, P_ = key
                 for seen, (k2, n2) in enumerate(reversed(self._cull_counts.items())):
                     if seen >= 256:
@@ -358,8 +391,10 @@ class ShardedTracer:
                     if isinstance(k2, tuple) and len(k2) == 4 and k2[0] == ident and k2[3] == P_ and \
                             min(b, k2[2]) - max(a, k2[1]) >= 0.75 * max(b - a, k2[2] - k2[1]):
                         g = int(n2 * (b - a) / max(k2[2] - k2[1], 1) * 1.15); break
+        if isinstance(key, tuple) and len(key) == 4 and key[0] is None:
+            g = None                                           # a ray set without a name: nothing is known about it, its count is read back
         st.set_option("cull_next", 0 if g is None else g + g // 4 + 4096)
-        self._cull_prev_key = key
+        self._cull_prev_key = key if not (isinstance(key, tuple) and len(key) == 4 and key[0] is None) else None
         self.cull_readbacks += 1 if g is None else 0
 
     def forward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, mod=1.0, rebuild=True, cull_key=None):
@@ -386,9 +421,9 @@ class ShardedTracer:
         self._rays_full = (ray_o, ray_d)
         cull = (self._ro, self._rd) if self.cull_build else None
         if cull is not None:
-            ident = cull_key if cull_key is not None else (ray_o.data_ptr(), ray_o._version, ray_d.data_ptr(), ray_d._version, tuple(ray_o.shape))
-            self._cull_sizing((ident, a, b, int(means.shape[0])))
+            self._cull_sizing((cull_key, a, b, int(means.shape[0])))
         if rebuild or cull is not None:                        # a ray-culled structure must be rebuilt for every ray set
+            self._build_id += 1
             if self._backend_takes(self.backend.build, "cull_rays"):
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)
             else:                                                                 # backend without culling (test stand-ins)
@@ -401,7 +436,7 @@ class ShardedTracer:
         # what backward() needs of THIS forward: an autograd Function keeps it in its ctx (renderer._ShardedTrace), so that a second
         # forward before loss.backward() -- an evaluation render, another frame -- cannot make the backward differentiate the wrong slab
         self.last_ctx = {"slab": (a, b), "ro": self._ro, "rd": self._rd, "out_loc": out_loc, "accum_loc": accum_loc,
-                         "serial": getattr(self.backend, "last_serial", None)}
+                         "serial": getattr(self.backend, "last_serial", None), "build_id": self._build_id, "mod": mod}
         if self.world == 1 and not self.force_collectives:
             return out_loc, accum_loc
         # all_gather needs equal shapes: slabs padded to the widest one; element 0 of the message = this rank's status word
@@ -430,8 +465,22 @@ class ShardedTracer:
     def backward(self, means, scales, rotations, opacities, shs, deg, bg, dL_full, mod=1.0,
                  reduce: bool = True, fwd_ctx=None) -> Dict[str, torch.Tensor]:
         """fwd_ctx: the `last_ctx` of the forward to differentiate (default: the most recent one).  When another forward has
-        replaced the library's hit record since, the local backward re-traces (forward_serial mismatch) -- same gradients."""
+        replaced the library's hit record since, the local backward re-traces (forward_serial mismatch) -- and when that forward also
+        REBUILT the structure (another frame's actor poses, another ray set's culled build, a rebalanced slab: ADVICE r04), the structure
+        of THIS forward is built again first: culled for its rays, sized exactly.  Same gradients."""
         fc = fwd_ctx if fwd_ctx is not None else self.last_ctx
+        if fc.get("build_id", self._build_id) != self._build_id:
+            cull = (fc["ro"], fc["rd"]) if self.cull_build else None
+            st_ = getattr(self.backend, "state", None)
+            if cull is not None and st_ is not None and hasattr(st_, "set_option"):
+                st_.set_option("cull_next", 0)                 # read the count back: nothing is known about the size any more
+                self._cull_prev_key = None
+            self._build_id += 1
+            if self._backend_takes(self.backend.build, "cull_rays"):
+                self.backend.build(means, scales, rotations, opacities, fc.get("mod", mod), cull_rays=cull)
+            else:
+                self.backend.build(means, scales, rotations, opacities, fc.get("mod", mod))
+            fc = dict(fc); fc["build_id"] = self._build_id; fc["serial"] = -1      # the hit record is not this forward's: re-trace
         a, b = fc["slab"]
         ro_, rd_, out_loc_, accum_loc_ = fc["ro"], fc["rd"], fc["out_loc"], fc["accum_loc"]
         dL = dL_full[:, a:b].contiguous()
@@ -451,6 +500,11 @@ class ShardedTracer:
             pz = lay.flat.is_cuda and hasattr(self.backend, "state") and (not exchanging or self.exchange == "sparse")
         if hasattr(self.backend, "state") and getattr(self, "_pz_set", None) != pz:
             self.backend.state.set_option("grads_prezeroed", 1 if pz else 0); self._pz_set = pz
+            self._flat_dirty, self._prev_lists = True, None                   # the protocol changed hands: nothing is known about the buffer
+        if not pz:
+            # a backward outside the prezero protocol writes every row of the flat buffer: the lists of an earlier prezero step no longer
+            # describe what is non-zero in it (stale rows survived in the returned views)
+            self._flat_dirty, self._prev_lists = True, None
         if pz:
             if self._flat_dirty or self._prev_lists is None:
                 lay.flat.zero_()                                           # first step / after an error / after a dense exchange
@@ -715,9 +769,10 @@ class ShardedTracer:
         rows into ``[off[B] | n[B] | idx[cap] | rows[cap][60]]`` (blocks of 1024 Gaussian indices), ONE all_gather moves the messages,
         ONE launch clears this rank's own rows and adds every rank's list in rank order, block by block (a block of indices is owned by
         one workgroup: bit-identical sums on all replicas).  Nothing is read back inside the step: the capacity is speculated (1.5 x the
-        largest list of the last 8 exchanges + 4096; the first exchange of a size: P / 4), the apply kernel raises a device flag when a
-        list did not fit (it skips the affected blocks), the flag and the list lengths travel to pinned memory asynchronously and the
-        NEXT forward's check() raises on all ranks alike (every rank saw the same messages) and raises the capacity."""
+        largest list of the last 8 exchanges + 4096; the first exchange of a size reads its counts back once), the apply kernel raises a
+        device flag when a list did not fit (it skips the affected blocks), the flag and the list lengths travel to pinned memory
+        asynchronously; a training loop reads them with verify_step() BEFORE its optimizer step and re-runs the step, any other caller gets
+        the NEXT forward's check(), which raises on all ranks alike (every rank saw the same messages); either way the capacity is raised."""
         P, M, N, rank = lay.P, lay.M, self.world, self.rank
         dev = lay.flat.device
         key = ("lists", P, M, N)
@@ -728,7 +783,14 @@ class ShardedTracer:
         elif self._cap_hist:
             cap = max(self._cap_hist) + max(self._cap_hist) // 2 + 4096
         else:
-            cap = max(P // 4, 65536)
+            # the first exchange of a size: nothing is known about the list lengths (round 4 guessed P / 4 and overflowed deterministically
+            # with 2-3 ranks or wide sectors: ADVICE r04).  ONE count read-back sizes it exactly -- the largest list over the ranks, so that
+            # every rank allocates the same message -- and later steps speculate from the measured lengths
+            n_own = (lay.views["accum"] > 0).sum().reshape(1).to(torch.int64)
+            dist.all_reduce(n_own, op=dist.ReduceOp.MAX, group=self.group)
+            biggest = int(self._to_host(n_own)[0])
+            cap = biggest + biggest // 2 + 4096
+            self.exchange_readbacks = getattr(self, "exchange_readbacks", 0) + 1
         cap = max(1, min(cap, max(P, 1)))
         words = self._xchg_words(lay, cap, True)
         msg = self._buf("xl_send", (words,), torch.int32, dev)

@@ -461,38 +461,63 @@ def training_step(scene: GaussianScene, frames: RangeFrames, frame, iteration: i
     if iteration % 1000 == 0:
         scene.oneupSHdegree()
     args = SimpleNamespace(dynamic=dynamic, opt=opt, pipe=SimpleNamespace())
-    pkg = raytracing(frame, scene.gaussians_assets, frames, background, args)
-    depth, intensity, raydrop = pkg["depth"].squeeze(-1), pkg["intensity"].squeeze(-1), pkg["raydrop"]
-    mask = frames.get_mask(frame)
-    gt_depth, gt_int = frames.get_depth(frame), frames.get_intensity(frame)
-    # masked means written as weighted sums: x[mask].mean() == (x * mask).sum() / mask.sum(), without the nonzero() + gather
-    # (and its host synchronisation) that boolean indexing costs on every call
-    mf = mask.to(depth.dtype)
-    n_valid = mf.sum().clamp_min(1.0)
-    mmean = lambda x: (x * mf).sum() / n_valid
-    loss_depth = opt.lambda_depth_l1 * mmean(torch.abs(depth - gt_depth))
-    loss_int = (opt.lambda_intensity_l1 * mmean(torch.abs(intensity - gt_int))
-                + opt.lambda_intensity_l2 * mmean((intensity - gt_int) ** 2)
-                + opt.lambda_intensity_dssim * (1 - ssim((intensity * mf).unsqueeze(0), (gt_int * mf).unsqueeze(0))))
-    labels = (1.0 - mf).reshape(-1, 1)                                # 1 = dropped ray (train.py:188-193)
-    loss_drop = opt.lambda_raydrop_bce * F.binary_cross_entropy(raydrop.reshape(-1, 1).clamp(1e-7, 1 - 1e-7), labels)
-    if opt.lambda_cd != 0:
-        pred_depth = depth.detach() if chamfer_points_detached else depth
-        gt_pts = frames.inverse_projection_with_range(frame, gt_depth)
-        pred_pts = frames.inverse_projection_with_range(frame, pred_depth)
-        d1, d2, _, _ = chamfer_3DDist()(pred_pts[None].contiguous(), gt_pts[None].contiguous())
-        loss_cd = opt.lambda_cd * (d1 + d2).mean() * 0.5
-    else:                                                             # weight 0: the term (and its HIP operator) is skipped
-        loss_cd = torch.zeros((), device=depth.device)
-    loss_reg = sum(opt.lambda_reg * g.box_reg_loss() for g in scene.gaussians_assets)
-    loss = loss_depth + loss_int + loss_drop + loss_cd + loss_reg
-    loss.backward()
+    from . import renderer as _rnd
+
+    def attempt():
+        """render -> losses -> backward (train.py:148-214); everything the optimizer step reads afterwards"""
+        pkg = raytracing(frame, scene.gaussians_assets, frames, background, args)
+        depth, intensity, raydrop = pkg["depth"].squeeze(-1), pkg["intensity"].squeeze(-1), pkg["raydrop"]
+        mask = frames.get_mask(frame)
+        gt_depth, gt_int = frames.get_depth(frame), frames.get_intensity(frame)
+        # masked means written as weighted sums: x[mask].mean() == (x * mask).sum() / mask.sum(), without the nonzero() + gather
+        # (and its host synchronisation) that boolean indexing costs on every call
+        mf = mask.to(depth.dtype)
+        n_valid = mf.sum().clamp_min(1.0)
+        mmean = lambda x: (x * mf).sum() / n_valid
+        loss_depth = opt.lambda_depth_l1 * mmean(torch.abs(depth - gt_depth))
+        loss_int = (opt.lambda_intensity_l1 * mmean(torch.abs(intensity - gt_int))
+                    + opt.lambda_intensity_l2 * mmean((intensity - gt_int) ** 2)
+                    + opt.lambda_intensity_dssim * (1 - ssim((intensity * mf).unsqueeze(0), (gt_int * mf).unsqueeze(0))))
+        labels = (1.0 - mf).reshape(-1, 1)                                # 1 = dropped ray (train.py:188-193)
+        loss_drop = opt.lambda_raydrop_bce * F.binary_cross_entropy(raydrop.reshape(-1, 1).clamp(1e-7, 1 - 1e-7), labels)
+        if opt.lambda_cd != 0:
+            pred_depth = depth.detach() if chamfer_points_detached else depth
+            gt_pts = frames.inverse_projection_with_range(frame, gt_depth)
+            pred_pts = frames.inverse_projection_with_range(frame, pred_depth)
+            d1, d2, _, _ = chamfer_3DDist()(pred_pts[None].contiguous(), gt_pts[None].contiguous())
+            loss_cd = opt.lambda_cd * (d1 + d2).mean() * 0.5
+        else:                                                             # weight 0: the term (and its HIP operator) is skipped
+            loss_cd = torch.zeros((), device=depth.device)
+        loss_reg = sum(opt.lambda_reg * g.box_reg_loss() for g in scene.gaussians_assets)
+        loss = loss_depth + loss_int + loss_drop + loss_cd + loss_reg
+        loss.backward()
+        return pkg, loss, loss_depth, loss_int, loss_drop, loss_cd
+
+    pkg, loss, loss_depth, loss_int, loss_drop, loss_cd = attempt()
+    redone = 0
+    if _rnd.sharded is not None and getattr(opt, "verify_sharded_step", True):
+        # Multi-GPU: a rank's culled build and the gradient exchange are sized SPECULATIVELY (no host wait inside the step).  A size that was too
+        # small is flagged on the device -- but an optimizer step taken on that step's incomplete gradients could not be undone.  So the step is
+        # verified HERE, between loss.backward() and scene.optimize (train.py:215-220): one wait for the status words every rank gathered.  A
+        # reported problem re-runs the step once with exact sizes (the gradients of the failed attempt are dropped); a second one raises with
+        # the parameters untouched.  Every rank takes the same branch: all ranks saw the same words.
+        bad = _rnd.sharded.verify_step()
+        if bad is not None:
+            for g_ in scene.gaussians_assets:
+                for p_ in g_._params().values():
+                    p_.grad = None
+            pkg, loss, loss_depth, loss_int, loss_drop, loss_cd = attempt()
+            redone = 1
+            bad = _rnd.sharded.verify_step()
+            if bad is not None:
+                from ._capi import LrtError
+                raise LrtError(f"sharded training step {iteration}: incomplete results on a rank in two attempts ({bad[0]}; per-rank words {bad[1]}); "
+                               "the optimizer step was NOT taken, the parameters are those of the previous iteration.  " + _rnd.sharded._STATUS_HELP)
     with torch.no_grad():
         info = scene.optimize(opt, iteration, pkg["means3D"].grad, pkg["accum_gaussian_weight"])
         # multi-GPU: the replicas are never synchronised (identical gradients + identical seeds keep them identical); verify it now and then
-        from . import renderer as _rnd
         k_chk = int(getattr(opt, "replica_check_interval", 500))
         if _rnd.sharded is not None and k_chk > 0 and iteration % k_chk == 0:
             _rnd.sharded.check_replicas([p_ for g in scene.gaussians_assets for p_ in g._params().values()])
     return {"loss": loss.detach(), "depth": loss_depth.detach(), "intensity": loss_int.detach(), "raydrop": loss_drop.detach(),
-            "chamfer": loss_cd.detach(), "densify": info, "points": sum(g._xyz.shape[0] for g in scene.gaussians_assets)}
+            "chamfer": loss_cd.detach(), "densify": info, "points": sum(g._xyz.shape[0] for g in scene.gaussians_assets), "step_redone": redone}

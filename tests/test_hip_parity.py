@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from tests.hip_util import run_hip, rel_l2, frac_outside, parity_report
+    from tests.hip_util import DEFAULT_OPTS as DEFAULT_OPTS_
 
 MODES = [{"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "bwd_mode": 1, "defer_colour": 0},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
@@ -191,6 +192,41 @@ def test_eval_mode_backward_retraces(s10k):
     h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, training=False)
     for k in GRADS:
         assert rel_l2(h["grads"][k].reshape(bw[k].shape), bw[k]) < 1e-3
+
+
+def test_retracing_backward_right_behind_a_build_sees_a_finished_tree():
+    """a fused build leaves the tree levels >= 4 to the NEXT forward's prologue.  build -> backward with no forward in
+    between (legal in the C ABI; the re-tracing backward walks the tree) must finish them itself: the sequence build(A), forward(A),
+    build(B), re-tracing backward(B) must give the gradients of build(B), forward(B), backward(B).  40,000 Gaussians: five tree levels."""
+    from lidar_rt_amd.parallel import HipBackend
+    dev = torch.device("cuda:0")
+    scB = scenes.make_scene(40_000, seed=5, radius_scale=0.4)
+    scA = {k: v.copy() for k, v in scB.items()}
+    scA["means"] = scA["means"] + np.array([7.0, -5.0, 0.5], np.float32)          # another tree top: stale boxes would cull the wrong space
+    o, d = scenes.kitti_rays(16, 128)
+    dL = scenes.upstream_grad(16, 128)
+    tB = {k: torch.as_tensor(v, device=dev) for k, v in scB.items()}
+    tA = {k: torch.as_tensor(v, device=dev) for k, v in scA.items()}
+    ro, rd, g_up = torch.as_tensor(o, device=dev), torch.as_tensor(d, device=dev), torch.as_tensor(dL, device=dev)
+    bg = torch.as_tensor(scenes.BG_DEFAULT, device=dev)
+    be = HipBackend()
+    for k, v in DEFAULT_OPTS_.items():
+        be.state.set_option(k, v)
+    be.state.set_option("bwd_mode", 0)                                              # the backward re-traces like the reference
+    argsB = (tB["means"], tB["scales"], tB["rotations"], tB["opacities"], tB["shs"], 3, bg)
+    argsA = (tA["means"], tA["scales"], tA["rotations"], tA["opacities"], tA["shs"], 3, bg)
+    be.build(*argsB[:4])
+    outB, _ = be.forward(ro, rd, *argsB)
+    ref = {k: v.clone() for k, v in be.backward(ro, rd, *argsB, outB, g_up).items()}
+    be.build(*argsA[:4]); be.forward(ro, rd, *argsA)
+    be.build(*argsB[:4])                                                            # no forward behind this build
+    got = be.backward(ro, rd, *argsB, outB, g_up)
+    torch.cuda.synchronize()
+    be.state.check(dev, wait=True)
+    be.state.set_option("bwd_mode", 3)
+    for k in ("means", "scales", "rotations", "opacities", "shs"):
+        assert float(ref[k].abs().sum()) > 0
+        assert rel_l2(got[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-5, k          # atomics: the order of the float additions differs
 
 
 # ---------------------------------------------------------------------------------- known answers / edge cases

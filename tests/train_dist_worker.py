@@ -57,14 +57,42 @@ def main():
     renderer.sharded = tr
     torch.manual_seed(1234)                                    # the split of densify_and_prune samples: the same draws on every rank
     log = []
+    # LRT_TEST_BAD_CULL = "once:<it>": before iteration <it> the counts remembered for the culled builds are replaced by 64 -- that step's build
+    # is sized far too small and loses primitives (error bit 8): training_step must notice BEFORE the optimizer step and redo the step;
+    # "always:<it>": every build of that iteration is under-sized: training_step must raise with the parameters untouched
+    bad_mode, bad_it = (os.environ.get("LRT_TEST_BAD_CULL", ":0").split(":") + ["0"])[:2]
+    redone, raised_clean = 0, -1
     for it in range(1, 6):
+        if bad_mode == "once" and it == int(bad_it):
+            for k_ in list(tr._cull_counts):
+                tr._cull_counts[k_] = 64
+        if bad_mode == "always" and it == int(bad_it):
+            orig_sizing = tr._cull_sizing
+            def too_small(key, _o=orig_sizing):
+                _o(key); tr.backend.state.set_option("cull_next", 64)
+            tr._cull_sizing = too_small
+            before = {n: p.detach().clone() for n, p in asset._params().items()}
+            m_before = asset.optimizer.state[asset._xyz]["exp_avg"].clone() if asset._xyz in asset.optimizer.state else None
+            try:
+                training.training_step(scene, frames, it % 3, it, opt, bg)
+                raised_clean = 0
+            except Exception as ex:                                     # LrtError on every rank alike
+                same = all(torch.equal(before[n], p.detach()) for n, p in asset._params().items())
+                if m_before is not None:
+                    same = same and torch.equal(m_before, asset.optimizer.state[asset._xyz]["exp_avg"])
+                raised_clean = 1 if (same and "NOT taken" in str(ex)) else 0
+            tr._cull_sizing = orig_sizing
+            for g_ in scene.gaussians_assets:
+                for p_ in g_._params().values():
+                    p_.grad = None
         r = training.training_step(scene, frames, it % 3, it, opt, bg)
+        redone += int(r.get("step_redone", 0))
         log.append([float(r["loss"]), float(r["points"])] + [float(x) for x in r["densify"]])
     tr.check()
     pr = {n: p.detach().cpu().numpy() for n, p in asset._params().items()}
     st = asset.optimizer.state[asset._xyz]
     np.savez(out_path + f".rank{rank}.npz", log=np.asarray(log), m_xyz=st["exp_avg"].cpu().numpy(), v_xyz=st["exp_avg_sq"].cpu().numpy(),
-             reruns=np.asarray([tr.exchange_reruns]), **pr)
+             reruns=np.asarray([tr.exchange_reruns]), redone=np.asarray([redone]), raised_clean=np.asarray([raised_clean]), **pr)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
