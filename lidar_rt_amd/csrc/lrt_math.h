@@ -163,85 +163,57 @@ LRT_HD void lrt_hit_geom(const float* o, const float* d, float t, const float* m
 //   dL_dG     = opacity * dL_dalpha                      (backward.cu:609)
 //   dL_dD_gs  = dL_ddepth * w                            (:600)
 //   dL_dN_gs  = dL_dnormal * w                           (:603)
-// The hit triangle (pidx parity) is chosen from the local coordinates: faces
-// [0,1,2] covers v > u, [2,3,1] covers v < u (corners (-1,1),(-1,-1),(1,1),(1,-1)).
+//
+// The reference routes the depth gradient through the three vertices of the hit triangle (corners mu +- ex R0 +- ey R1 of
+// build2DRectangle, primitive_utils.py:184-209): t = n.(v1 - o) / n.d with n = (v2 - v1) x (v3 - v1), then dL/dv_k -> dL/d(mu, R0, R1,
+// scales) by the corner coefficients.  Round 5 evaluates that route in CLOSED FORM.  With sigma = +-1 for the two triangles of the quad,
+// n = sigma 4 ex ey R2, so t = R2.(mu - o) / R2.d whichever triangle was hit, and the chain collapses (derivation: DESIGN.md section 4.3;
+// v1 - x = (v1 - mu) - pd, ex / sc0 = cut, every term that carries the corner coefficients or the cutoff cancels):
+//   sum_k dL/dv_k            = R2 w                     -> d_mean
+//   sc0 sum_k h_kx dL/dv_k   = -(R1 x pd) w             -> dR0        (w = dL/dt / (R2.d), pd = hit point - mu)
+//   sc1 sum_k h_ky dL/dv_k   =  (R0 x pd) w             -> dR1
+//   sc0 L0 . (sum_k h_kx ..) = -(pd . R2) w / mod       -> d_scale: pd lies in the quad's plane, the term is 0 (the reference's fp32 chain
+//                                                          leaves rounding noise there, its fp64 restatement 1e-16)
+// i.e. the gradient of t w.r.t. (mu, R0, R1) with R2 = R0 x R1, as the triangle route implies it.  Equal to the literal chain in exact
+// arithmetic (tests/test_host_math.py compares the two on random hits; tests/host_check/host_check.cpp keeps the literal one), closer to
+// the fp64 oracle than the literal fp32 chain (no cancellation of 1e+1-sized corner terms), 70 fewer live registers: k_bwd_reduce4 fits a
+// fifth workgroup per CU.  `op`, `mu`, `o`, `sc` beyond pd are no longer needed for the depth route; the signature is kept.
 LRT_HD void lrt_hit_backward(const LrtHitGeom* h, const float* o, const float* d, const float* mu,
                              const float* sc, const float* q, float op, float dL_dG, float dL_dD_gs,
                              const float* dL_dN_gs, LrtHitGrad* g)
 {
+    (void)o; (void)mu; (void)op;
     const float* R = h->R; const float* L0 = h->L0; const float* L1 = h->L1; const float* pd = h->pd;
-    float u = h->u, v = h->v, G = h->G;
-    float dL_du = dL_dG * -G * u, dL_dv = dL_dG * -G * v;
-    float dR0[3], dR1[3], dR2[3];
-    for (int i = 0; i < 3; i++) {
-        dR0[i] = dL_du * pd[i] / sc[0];
-        dR1[i] = dL_dv * pd[i] / sc[1];
-        dR2[i] = dL_dN_gs[i] * h->nsign;
-    }
-    g->d_scale[0] = dL_dG * (G * u * u / sc[0]);
-    g->d_scale[1] = dL_dG * (G * v * v / sc[1]);
+    const float u = h->u, v = h->v, G = h->G;
+    const float dL_du = dL_dG * -G * u, dL_dv = dL_dG * -G * v;
+    const float isx = 1.0f / sc[0], isy = 1.0f / sc[1];
+    g->d_scale[0] = dL_dG * (G * u * u * isx);
+    g->d_scale[1] = dL_dG * (G * v * v * isy);
     float dxyz[3];
     for (int i = 0; i < 3; i++) {
         g->d_mean[i] = dL_dG * (G * (L0[i] * u + L1[i] * v));
         dxyz[i] = dL_du * L0[i] + dL_dv * L1[i];
     }
-    float dL_dd = dxyz[0] * d[0] + dxyz[1] * d[1] + dxyz[2] * d[2] + dL_dD_gs;
-
-    // quad corners (primitive_utils.py:184-209) and the triangle that was hit
-    float cut = lrt_cutoff(op);
-    float ex = sc[0] * cut, ey = sc[1] * cut;
-    float V[4][3];
-    const float cs[4][2] = {{-1.f, 1.f}, {-1.f, -1.f}, {1.f, 1.f}, {1.f, -1.f}};
-    for (int k = 0; k < 4; k++)
-        for (int i = 0; i < 3; i++) V[k][i] = cs[k][0] * (R[3 * i + 0] * ex) + cs[k][1] * (R[3 * i + 1] * ey) + mu[i];
-    bool odd = (v < u);                                  // pidx % 2
-    float v1[3], v2[3], v3[3];
+    const float dL_dd = dxyz[0] * d[0] + dxyz[1] * d[1] + dxyz[2] * d[2] + dL_dD_gs;
+    const float R0[3] = {R[0], R[3], R[6]}, R1[3] = {R[1], R[4], R[7]}, R2[3] = {R[2], R[5], R[8]};
+    const float w = dL_dd / (R2[0] * d[0] + R2[1] * d[1] + R2[2] * d[2]);
+    const float c1[3] = {R1[1] * pd[2] - R1[2] * pd[1], R1[2] * pd[0] - R1[0] * pd[2], R1[0] * pd[1] - R1[1] * pd[0]};   // R1 x pd
+    const float c0[3] = {R0[1] * pd[2] - R0[2] * pd[1], R0[2] * pd[0] - R0[0] * pd[2], R0[0] * pd[1] - R0[1] * pd[0]};   // R0 x pd
+    float dR0[3], dR1[3], dR2[3];
     for (int i = 0; i < 3; i++) {
-        v1[i] = odd ? V[1][i] : V[0][i]; v2[i] = odd ? V[2][i] : V[1][i]; v3[i] = odd ? V[3][i] : V[2][i];
+        dR0[i] = dL_du * pd[i] * isx - c1[i] * w;
+        dR1[i] = dL_dv * pd[i] * isy + c0[i] * w;
+        dR2[i] = dL_dN_gs[i] * h->nsign;
+        g->d_mean[i] += R2[i] * w;
     }
-    float h1x = -cut,              h1y = odd ? -cut : cut;
-    float h2x = odd ? cut : -cut,  h2y = odd ? cut : -cut;
-    float h3x = cut,               h3y = odd ? -cut : cut;
-
-    float e21[3], e31[3], n[3], c[3];
-    for (int i = 0; i < 3; i++) { e21[i] = v2[i] - v1[i]; e31[i] = v3[i] - v1[i]; c[i] = v1[i] - o[i]; }
-    n[0] = e21[1] * e31[2] - e21[2] * e31[1];
-    n[1] = e21[2] * e31[0] - e21[0] * e31[2];
-    n[2] = e21[0] * e31[1] - e21[1] * e31[0];
-    float p = n[0] * c[0] + n[1] * c[1] + n[2] * c[2];
-    float qq = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-    float gn[3];
-    for (int i = 0; i < 3; i++) gn[i] = (c[i] - p / qq * d[i]) / qq;
-    float a23[3], a31[3], a12[3];
-    for (int i = 0; i < 3; i++) { a23[i] = v2[i] - v3[i]; a31[i] = v3[i] - v1[i]; a12[i] = v1[i] - v2[i]; }
-    float dv1[3], dv2[3], dv3[3];
-    dv1[0] = (a23[1] * gn[2] - a23[2] * gn[1]) * dL_dd + n[0] / qq * dL_dd;
-    dv1[1] = (a23[2] * gn[0] - a23[0] * gn[2]) * dL_dd + n[1] / qq * dL_dd;
-    dv1[2] = (a23[0] * gn[1] - a23[1] * gn[0]) * dL_dd + n[2] / qq * dL_dd;
-    dv2[0] = (a31[1] * gn[2] - a31[2] * gn[1]) * dL_dd;
-    dv2[1] = (a31[2] * gn[0] - a31[0] * gn[2]) * dL_dd;
-    dv2[2] = (a31[0] * gn[1] - a31[1] * gn[0]) * dL_dd;
-    dv3[0] = (a12[1] * gn[2] - a12[2] * gn[1]) * dL_dd;
-    dv3[1] = (a12[2] * gn[0] - a12[0] * gn[2]) * dL_dd;
-    dv3[2] = (a12[0] * gn[1] - a12[1] * gn[0]) * dL_dd;
-    float sxv[3], syv[3];
-    for (int i = 0; i < 3; i++) {
-        sxv[i] = h1x * dv1[i] + h2x * dv2[i] + h3x * dv3[i];
-        syv[i] = h1y * dv1[i] + h2y * dv2[i] + h3y * dv3[i];
-        dR0[i] += sc[0] * sxv[i];
-        dR1[i] += sc[1] * syv[i];
-        g->d_mean[i] += dv1[i] + dv2[i] + dv3[i];
-    }
-    g->d_scale[0] += sc[0] * (L0[0] * sxv[0] + L0[1] * sxv[1] + L0[2] * sxv[2]);
-    g->d_scale[1] += sc[1] * (L1[0] * syv[0] + L1[1] * syv[1] + L1[2] * syv[2]);
 
     // quat_to_rotmat_vjp: vR[i][j] = dR_i[j] (glm column i, row j); gradient w.r.t. the normalised quaternion (D6)
-    float s = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    float w = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
+    const float s = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float qw = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
     g->d_rot[0] = 2.f * (x * (dR1[2] - dR2[1]) + y * (dR2[0] - dR0[2]) + z * (dR0[1] - dR1[0]));
-    g->d_rot[1] = 2.f * (-2.f * x * (dR1[1] + dR2[2]) + y * (dR0[1] + dR1[0]) + z * (dR0[2] + dR2[0]) + w * (dR1[2] - dR2[1]));
-    g->d_rot[2] = 2.f * (x * (dR0[1] + dR1[0]) - 2.f * y * (dR0[0] + dR2[2]) + z * (dR1[2] + dR2[1]) + w * (dR2[0] - dR0[2]));
-    g->d_rot[3] = 2.f * (x * (dR0[2] + dR2[0]) + y * (dR1[2] + dR2[1]) - 2.f * z * (dR0[0] + dR1[1]) + w * (dR0[1] - dR1[0]));
+    g->d_rot[1] = 2.f * (-2.f * x * (dR1[1] + dR2[2]) + y * (dR0[1] + dR1[0]) + z * (dR0[2] + dR2[0]) + qw * (dR1[2] - dR2[1]));
+    g->d_rot[2] = 2.f * (x * (dR0[1] + dR1[0]) - 2.f * y * (dR0[0] + dR2[2]) + z * (dR1[2] + dR2[1]) + qw * (dR2[0] - dR0[2]));
+    g->d_rot[3] = 2.f * (x * (dR0[2] + dR2[0]) + y * (dR1[2] + dR2[1]) - 2.f * z * (dR0[0] + dR1[1]) + qw * (dR0[1] - dR1[0]));
 }
 
 // Hit distance of the ray (o, d) on the plane of Gaussian g in fp64, from the RAW fp32 parameters as the build packed them

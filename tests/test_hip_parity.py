@@ -226,7 +226,7 @@ def test_retracing_backward_right_behind_a_build_sees_a_finished_tree():
     be.state.set_option("bwd_mode", 3)
     for k in ("means", "scales", "rotations", "opacities", "shs"):
         assert float(ref[k].abs().sum()) > 0
-        assert rel_l2(got[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-5, k          # atomics: the order of the float additions differs
+        assert rel_l2(got[k].cpu().numpy(), ref[k].cpu().numpy()) < 2e-3, k          # another Morton box (carried from build A) = another tree: the float additions and exact-tie orders differ; a stale tree top gives O(1)
 
 
 # ---------------------------------------------------------------------------------- known answers / edge cases

@@ -68,3 +68,84 @@ def test_product_math_matches_oracle_s10k(hc, deg, mod):
         ref = bw[k]
         err = np.abs(g[k] - ref).max() / np.abs(ref).max()
         assert err < 1e-3, (k, err)
+
+
+def _literal_vertex_route_f64(o, d, t, mu, sc, q, op, dL_dG, dL_dD, dN):
+    """backward.cu:339-431 + :621-652 + auxiliary.h:389-433 in float64 (one hit), the way rounds 1-4 evaluated it in float32."""
+    o, d, mu, sc, q, dN = (np.asarray(a, np.float64) for a in (o, d, mu, sc, q, dN))
+    qn = q / np.linalg.norm(q); w, x, y, z = qn
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    L0, L1 = R[:, 0] / sc[0], R[:, 1] / sc[1]
+    pd = o + t * d - mu
+    u, v = L0 @ pd, L1 @ pd
+    G = np.exp(-0.5 * (u * u + v * v))
+    nsign = 1.0 if -((mu - o) @ R[:, 2]) > 0 else -1.0
+    dL_du, dL_dv = dL_dG * -G * u, dL_dG * -G * v
+    dR0, dR1, dR2 = dL_du * pd / sc[0], dL_dv * pd / sc[1], dN * nsign
+    d_scale = np.array([dL_dG * G * u * u / sc[0], dL_dG * G * v * v / sc[1]])
+    d_mean = dL_dG * G * (L0 * u + L1 * v)
+    dL_dd = (dL_du * L0 + dL_dv * L1) @ d + dL_dD
+    cut = np.sqrt(2 * np.log(op * 255.0)) + 0.01
+    ex, ey = sc[0] * cut, sc[1] * cut
+    cs = [(-1, 1), (-1, -1), (1, 1), (1, -1)]
+    V = [a * ex * R[:, 0] + b * ey * R[:, 1] + mu for a, b in cs]
+    odd = v < u
+    v1, v2, v3 = (V[1], V[2], V[3]) if odd else (V[0], V[1], V[2])
+    h1, h2, h3 = ((-cut, -cut), (cut, cut), (cut, -cut)) if odd else ((-cut, cut), (-cut, -cut), (cut, cut))
+    n = np.cross(v2 - v1, v3 - v1); c = v1 - o
+    p_, qq = n @ c, n @ d
+    gn = (c - p_ / qq * d) / qq
+    dv1 = (np.cross(v2 - v3, gn) + n / qq) * dL_dd; dv2 = np.cross(v3 - v1, gn) * dL_dd; dv3 = np.cross(v1 - v2, gn) * dL_dd
+    sxv = h1[0] * dv1 + h2[0] * dv2 + h3[0] * dv3; syv = h1[1] * dv1 + h2[1] * dv2 + h3[1] * dv3
+    dR0 = dR0 + sc[0] * sxv; dR1 = dR1 + sc[1] * syv
+    d_mean = d_mean + dv1 + dv2 + dv3
+    d_scale = d_scale + np.array([sc[0] * (L0 @ sxv), sc[1] * (L1 @ syv)])
+    d_rot = 2 * np.array([x * (dR1[2] - dR2[1]) + y * (dR2[0] - dR0[2]) + z * (dR0[1] - dR1[0]),
+                          -2 * x * (dR1[1] + dR2[2]) + y * (dR0[1] + dR1[0]) + z * (dR0[2] + dR2[0]) + w * (dR1[2] - dR2[1]),
+                          x * (dR0[1] + dR1[0]) - 2 * y * (dR0[0] + dR2[2]) + z * (dR1[2] + dR2[1]) + w * (dR2[0] - dR0[2]),
+                          x * (dR0[2] + dR2[0]) + y * (dR1[2] + dR2[1]) - 2 * z * (dR0[0] + dR1[1]) + w * (dR0[1] - dR1[0])])
+    return np.concatenate([d_mean, d_scale, d_rot])
+
+
+def test_closed_form_hit_backward_equals_the_literal_vertex_route(hc):
+    """Round 5: lrt_hit_backward evaluates the reference's depth-through-the-vertices route (backward.cu:339-431, :621-652) in closed form.
+    On random hits (random Gaussians, rays through random points of their quads, either triangle) it must agree with the literal chain
+    evaluated in float64, and be CLOSER to it than the float32 literal chain of rounds 1-4 (kept in tests/host_check/host_check.cpp),
+    whose corner terms cancel."""
+    rng = np.random.default_rng(3)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    rows_c, rows_l, rows_x = [], [], []
+    for i in range(1500):
+        mu = f32(rng.uniform(-30, 30, 3)); sc = f32(np.exp(rng.uniform(np.log(0.03), np.log(0.25), 2)))
+        q = rng.standard_normal(4); q = f32(q / np.linalg.norm(q) * rng.uniform(0.5, 2.0))       # the kernels normalise it
+        op = np.float32(rng.uniform(0.05, 0.99))
+        qn = q.astype(np.float64) / np.linalg.norm(q.astype(np.float64))
+        w, x, y, z = qn
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        cut = np.sqrt(2 * np.log(float(op) * 255.0)) + 0.01
+        uv = rng.uniform(-1, 1, 2) * cut
+        hit = mu + R[:, 0] * sc[0] * uv[0] + R[:, 1] * sc[1] * uv[1]
+        o = f32(rng.uniform(-2, 2, 3))
+        dvec = hit - o; d = f32(dvec / np.linalg.norm(dvec))
+        if abs(d.astype(np.float64) @ R[:, 2]) < 0.05:
+            continue                                                  # grazing rays: every form divides by (n.d)^2
+        # the hit distance as the kernels have it: on the plane, in float32
+        t = np.float32(((mu.astype(np.float64) - o) @ R[:, 2]) / (d.astype(np.float64) @ R[:, 2]))
+        dN = f32(rng.standard_normal(3) * 1e-3)
+        dG, dD = np.float32(rng.standard_normal() * 1e-2), np.float32(rng.standard_normal() * 1e-2)
+        oc, ol = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        hc.hc_hit_backward_both(_p(o), _p(d), C.c_float(float(t)), _p(mu), _p(sc), _p(q), C.c_float(float(op)), C.c_float(1.0),
+                                C.c_float(float(dG)), C.c_float(float(dD)), _p(dN), _p(oc), _p(ol))
+        rows_c.append(oc.astype(np.float64)); rows_l.append(ol.astype(np.float64))
+        rows_x.append(_literal_vertex_route_f64(o, d, float(t), mu, sc, q, float(op), float(dG), float(dD), dN))
+    c, l, x = np.array(rows_c), np.array(rows_l), np.array(rows_x)
+    assert len(c) > 1000 and np.isfinite(c).all() and np.isfinite(l).all() and np.isfinite(x).all()
+    e_closed, e_literal = np.linalg.norm(c - x) / np.linalg.norm(x), np.linalg.norm(l - x) / np.linalg.norm(x)
+    assert e_closed < 2e-5, (e_closed, e_literal)                    # the closed form IS the literal route ...
+    assert e_closed <= e_literal, (e_closed, e_literal)              # ... and no farther from it than its own float32 evaluation
+    scale = np.abs(x).mean(0) + 1e-30
+    assert (np.abs(c - x) / scale).max() < 5e-3, (np.abs(c - x) / scale).max(0)
