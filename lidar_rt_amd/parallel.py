@@ -186,6 +186,7 @@ class ShardedTracer:
         self._t_events, self._t_last_ms, self._times = None, 0.0, None
         self._cull_counts, self._cull_prev_key, self.cull_readbacks = collections.OrderedDict(), None, 0     # see _cull_sizing
         self._cull_exact_next = False  # the next culled build reads its count back (after error 8, see _drain)
+        self._xchg_exact_next = False  # the next device-side exchange reads its list lengths back (after any reported problem)
         self._build_id = 0             # counts the builds of this tracer: a backward re-traces only in the structure its forward used (see backward)
 
     # ---- per-phase timing of the collective regions (bench.py --gpus N: build / forward / backward come from the library's HIP events)
@@ -253,6 +254,8 @@ class ShardedTracer:
                 bad = (what, vals)
         self._pending = still
         if bad is not None:
+            self._xchg_exact_next = True                           # whatever went wrong: the next exchange reads its list lengths back (a step that is
+            #                                                        redone must not inherit a capacity learnt from the incomplete attempt)
             if hasattr(self.backend, "clear_errors") and getattr(self, "_dev", None) is not None and self._dev.type == "cuda":
                 self.backend.clear_errors(self._dev)
             if bad[0].startswith("forward") and any(int(v) & 8 for v in bad[1]):
@@ -778,11 +781,12 @@ class ShardedTracer:
         key = ("lists", P, M, N)
         if self._cap_key != key:
             self._cap_key, self._cap_hist = key, []
-        if self.first_cap is not None and not self._cap_hist:
+        if self.first_cap is not None and not self._cap_hist and not self._xchg_exact_next:
             cap = int(self.first_cap)
-        elif self._cap_hist:
+        elif self._cap_hist and not self._xchg_exact_next:
             cap = max(self._cap_hist) + max(self._cap_hist) // 2 + 4096
         else:
+            self._xchg_exact_next = False
             # the first exchange of a size: nothing is known about the list lengths (round 4 guessed P / 4 and overflowed deterministically
             # with 2-3 ranks or wide sectors: ADVICE r04).  ONE count read-back sizes it exactly -- the largest list over the ranks, so that
             # every rank allocates the same message -- and later steps speculate from the measured lengths

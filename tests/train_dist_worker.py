@@ -57,15 +57,17 @@ def main():
     renderer.sharded = tr
     torch.manual_seed(1234)                                    # the split of densify_and_prune samples: the same draws on every rank
     log = []
-    # LRT_TEST_BAD_CULL = "once:<it>": before iteration <it> the counts remembered for the culled builds are replaced by 64 -- that step's build
-    # is sized far too small and loses primitives (error bit 8): training_step must notice BEFORE the optimizer step and redo the step;
+    # LRT_TEST_BAD_CULL = "once:<it>": the first culled build of iteration <it> is sized for 64 primitives -- far too small, it loses primitives
+    # (error bit 8): training_step must notice BEFORE the optimizer step and redo the step;
     # "always:<it>": every build of that iteration is under-sized: training_step must raise with the parameters untouched
     bad_mode, bad_it = (os.environ.get("LRT_TEST_BAD_CULL", ":0").split(":") + ["0"])[:2]
     redone, raised_clean = 0, -1
     for it in range(1, 6):
         if bad_mode == "once" and it == int(bad_it):
-            for k_ in list(tr._cull_counts):
-                tr._cull_counts[k_] = 64
+            sizing_ = tr._cull_sizing
+            def too_small_once(key, _o=sizing_):
+                _o(key); tr.backend.state.set_option("cull_next", 64); tr._cull_sizing = _o
+            tr._cull_sizing = too_small_once
         if bad_mode == "always" and it == int(bad_it):
             orig_sizing = tr._cull_sizing
             def too_small(key, _o=orig_sizing):
