@@ -35,6 +35,8 @@
 #include "../../include/lrt.h"
 #include "lrt_math.h"
 
+// workgroups (one wave each) of the near-ray replay: normally the list is empty and all of them return at once
+#define LRT_NEAR_BLOCKS 1536
 #ifndef LRT_LEAF
 #define LRT_LEAF 8            // primitives per leaf (tested exhaustively by the packet)
 #endif
@@ -1710,7 +1712,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
 #undef LRT_CR4
             }
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
-            lrt_launch(st->lrec, k_fwd_near, dim3(64), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
+            lrt_launch(st->lrec, k_fwd_near, dim3(LRT_NEAR_BLOCKS), dim3(64), 0, stream, tp, rec_, naos_, dfr ? 1 : 0);
             if (dfr) {
                 const int np_ = ((int)HW + 1) / 2;                                                          // two rays per wave
                 const int cb = np_ < 256 * 32 ? (np_ >= 64 ? np_ & ~7 : np_) : 256 * 32;                  // a multiple of 8 (one azimuth sector per XCD) unless tiny
@@ -1729,7 +1731,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         rc = launch_trace(st, tp, false, stream);
         if (rc) return rc;
         tp.ovf_list = nullptr;
-        if (HW > 0 && P > 0) lrt_launch(st->lrec, k_fwd_near, dim3(64), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
+        if (HW > 0 && P > 0) lrt_launch(st->lrec, k_fwd_near, dim3(LRT_NEAR_BLOCKS), dim3(64), 0, stream, tp, (const float*)st->rec, (const float*)st->nodes_aos, 0);
     }
     // epilogue: colours of the hits beyond the record (deferred colour), status words -> host-mapped block, sticky error bits
     if (!fin_done) lrt_launch(st->lrec, k_fwd_fin, dim3(tp.ovf_list ? 64 : 1), dim3(256), 0, stream, tp, st->ctrl, st->status_dev);
