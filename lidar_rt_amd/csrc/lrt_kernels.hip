@@ -309,6 +309,14 @@ __device__ __forceinline__ float wave_sum_f(float x)                     // tota
     x += dpp_f<0x143, 0xc>(0.f, x);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+__device__ __forceinline__ float wave_min_f(float x)                     // minimum over the 64 lanes, in every lane (DPP scan: no lane-index registers, unlike __shfl_xor)
+{
+    x = fminf(x, dpp_f<0x111, 0xf>(3.0e38f, x)); x = fminf(x, dpp_f<0x112, 0xf>(3.0e38f, x)); x = fminf(x, dpp_f<0x114, 0xf>(3.0e38f, x)); x = fminf(x, dpp_f<0x118, 0xf>(3.0e38f, x));
+    x = fminf(x, dpp_f<0x142, 0xa>(3.0e38f, x));
+    x = fminf(x, dpp_f<0x143, 0xc>(3.0e38f, x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_max_f(float x) { return -wave_min_f(-x); }
 __device__ __forceinline__ float half_incl_prod(float x)                 // inclusive prefix product inside lanes 0..31 and inside 32..63
 {
     x *= dpp_f<0x111, 0xf>(1.f, x); x *= dpp_f<0x112, 0xf>(1.f, x); x *= dpp_f<0x114, 0xf>(1.f, x); x *= dpp_f<0x118, 0xf>(1.f, x);
@@ -846,7 +854,7 @@ lrt_state* lrt_create(int device)
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
-    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = 4; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
+    st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
     if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
@@ -1666,7 +1674,10 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             // any launch whose tiles composited >= 1024 hits on average in the last completed frame of this size.
             const bool heavy_tiles = st->est_valid && st->est_hw == HW && (size_t)st->est_hits >= (size_t)1024 * (size_t)tp.n_tiles;
             const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : ((tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
-            const int per_cu = nw == 8 ? (st->wg4_per_cu + 1) / 2 : st->wg4_per_cu;
+            // resident workgroups only: a workgroup that has to wait for a slot costs more than it brings (measured: 5 launched on 4 slots, forward +3 %).
+            // 8-wave groups: half as many; the non-deferred and the statistics instantiations are compiled for 2 (4-wave) / 1 (8-wave) per CU
+            int per_cu = nw == 8 ? max(1, st->wg4_per_cu / 2) : st->wg4_per_cu;
+            if (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr) per_cu = min(per_cu, nw == 8 ? 1 : 2);
             if (wg4 && tp.c4_qlimit < 64u * (unsigned)nw + 8u) tp.c4_qlimit = 64u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
             int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;

@@ -5,7 +5,7 @@ import torch
 from lidar_rt_amd.diff_lidar_tracer import Tracer, TracingSettings
 
 DEV = torch.device("cuda:0")
-DEFAULT_OPTS = {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "hit_cap": 256, "wg4_per_cu": 4, "c4_queue_limit": 1024, "c4_waves": 0, "slab0_mm": 100000, "root_nodes": 32, "learn_slab": 1, "spec_bwd": 1, "spec_margin": 65536, "own_sort": 2, "fused_tree": 1, "fused_hist": 1}     # the library defaults
+DEFAULT_OPTS = {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "hit_cap": 256, "wg4_per_cu": 5, "c4_queue_limit": 1024, "c4_waves": 0, "slab0_mm": 100000, "root_nodes": 32, "learn_slab": 1, "spec_bwd": 1, "spec_margin": 65536, "own_sort": 2, "fused_tree": 1, "fused_hist": 1}     # the library defaults
 
 
 def settings(bg, deg, mod=1.0):
