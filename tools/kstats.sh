@@ -5,7 +5,7 @@ TAG=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/ks_$TAG
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-both-paths --min-seconds 0 "$@" > $OUT/bench.json 2> $OUT/err.txt
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-both-paths --no-vary --min-seconds 0 "$@" > $OUT/bench.json 2> $OUT/err.txt
 find $OUT -name "*kernel_trace.csv" -delete
 python3 - <<PY
 import csv,glob
