@@ -962,7 +962,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
-    if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4 or 8"); st->c4_waves = value; return LRT_OK; }
+    if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
         int l2 = -1;
@@ -1673,11 +1673,16 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             // win at every tile count (10624 tiles: 2.35 vs 2.42 ms; 2656: 0.54 vs 0.73).  So: 8 waves for launches of up to 3072 tiles, and for
             // any launch whose tiles composited >= 1024 hits on average in the last completed frame of this size.
             const bool heavy_tiles = st->est_valid && st->est_hw == HW && (size_t)st->est_hits >= (size_t)1024 * (size_t)tp.n_tiles;
-            const int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : ((tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
+            // Round 5: 16 waves per tile (one workgroup per CU, 4096-entry rings) for launches of up to 1536 tiles -- a rank of an 8-way split: S1M 1024 tiles,
+            // forward 0.153 / 0.140 -> 0.147 / 0.137 ms (ranks 0 / 4), the Waymo-4M shape 1344 tiles, 0.480 / 0.330 -> 0.422 / 0.300 ms; on the full S1M frame
+            // (8192 tiles) 16 waves lose badly (0.94 against 0.63 ms): a tile's rounds do not get shorter in proportion, the barrier spans 1024 threads
+            int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 6 ? 16 : (tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
+            if (nw == 16 && (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr || st->c4_qlimit < C4_NQ)) nw = 8;      // 16 waves: the production variant only (and not with a lowered queue limit, a test option sized for the 1024-entry rings)
             // resident workgroups only: a workgroup that has to wait for a slot costs more than it brings (measured: 5 launched on 4 slots, forward +3 %).
             // 8-wave groups: half as many; the non-deferred and the statistics instantiations are compiled for 2 (4-wave) / 1 (8-wave) per CU
-            int per_cu = nw == 8 ? max(1, st->wg4_per_cu / 2) : st->wg4_per_cu;
-            if (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr) per_cu = min(per_cu, nw == 8 ? 1 : 2);
+            int per_cu = nw == 16 ? 1 : nw == 8 ? 2 : st->wg4_per_cu;
+            if (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr) per_cu = min(per_cu, nw == 4 ? 2 : 1);
+            if (nw == 16 && tp.c4_qlimit >= (unsigned)C4_NQ) tp.c4_qlimit = (unsigned)C4_NQ_OF(16);      // the 16-wave instantiation's rings hold 4096 entries
             if (wg4 && tp.c4_qlimit < 64u * (unsigned)nw + 8u) tp.c4_qlimit = 64u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
             int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;
@@ -1718,7 +1723,8 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
                 const dim3 g_(blocks), b_(64 * nw);
 #define LRT_CR4(D_, N_, S_) lrt_launch(st->lrec, (k_fwd_cr4<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
-                if (wg4 && nw == 8) { if (dfr) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); } else { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); } }
+                if (wg4 && nw == 16 && dfr && !sts) LRT_CR4(true, 16, false);      // (the statistics / non-deferred variants exist for 4 and 8 waves only)
+                else if (wg4 && nw >= 8) { if (dfr) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); } else { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); } }
                 else                { if (dfr) { if (sts) LRT_CR4(true, 4, true); else LRT_CR4(true, 4, false); } else { if (sts) LRT_CR4(false, 4, true); else LRT_CR4(false, 4, false); } }
 #undef LRT_CR4
             }

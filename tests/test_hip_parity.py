@@ -29,7 +29,8 @@ MODES = [{"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_m
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 0, "defer_colour": 1},
          {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 1}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 0},
-         {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 3}]
+         {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 3},
+         {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "c4_waves": 16}]
 GRADS = ("means", "scales", "rotations", "opacities", "shs")
 
 

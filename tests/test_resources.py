@@ -18,16 +18,20 @@ def table():
 
 def test_every_cr4_instantiation_is_free_of_vector_spills_and_scratch(table):
     cr4 = {n: r for n, r in table.items() if re.search(r"^k_fwd_cr4<", n)}
-    # DEFER_COLOUR x waves per tile {4, 8} x STATS: all eight are shipped (options fwd_mode / defer_colour / c4_waves / the counters)
-    assert len(cr4) == 8, sorted(cr4)
+    # DEFER_COLOUR x waves per tile {4, 8} x STATS, plus the 16-wave production variant: all nine are shipped (options fwd_mode /
+    # defer_colour / c4_waves / the counters)
+    assert len(cr4) == 9, sorted(cr4)
     assert resources.violations(table) == []
     for n, r in cr4.items():
         assert r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0 and not r["dynamic_stack"], (n, r)
-    # the production launches are held at 96 registers = 5 workgroups of 4 waves (2 of 8) per CU, and their LDS allows that
-    for n in ("k_fwd_cr4<true, 4, false>", "k_fwd_cr4<true, 8, false>"):
-        assert cr4[n]["vgpr"] + cr4[n]["agpr"] <= 96, (n, cr4[n])
+    # the 4-wave production launch is held at 96 registers = 5 workgroups per CU; 8 / 16 waves per tile: 2 / 1 workgroups (128 registers);
+    # their LDS allows that
+    assert cr4["k_fwd_cr4<true, 4, false>"]["vgpr"] + cr4["k_fwd_cr4<true, 4, false>"]["agpr"] <= 96
+    for n in ("k_fwd_cr4<true, 8, false>", "k_fwd_cr4<true, 16, false>"):
+        assert cr4[n]["vgpr"] + cr4[n]["agpr"] <= 128, (n, cr4[n])
     assert cr4["k_fwd_cr4<true, 4, false>"]["workgroups_per_cu"] == 5
     assert cr4["k_fwd_cr4<true, 8, false>"]["workgroups_per_cu"] == 2
+    assert cr4["k_fwd_cr4<true, 16, false>"]["workgroups_per_cu"] == 1
 
 
 def test_gate_fails_on_a_spilling_kernel(table):
