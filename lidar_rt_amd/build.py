@@ -31,9 +31,20 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+STAMP = os.path.join(CSRC, "liblrt_hip.srchash")       # the hash of the sources the in-tree library was compiled from (travels with it; git-ignored)
+
+
 def is_stale() -> bool:
+    """The library is rebuilt when it is missing or was compiled from OTHER sources: decided by the content hash written next to it,
+    not by modification times (a checkout, a copy to the GPU box or a touched header change mtimes without changing a byte -- and the
+    other way round).  A library without a stamp (built by hand) falls back to the mtime rule."""
     if not os.path.exists(LIB):
         return True
+    if os.path.exists(STAMP):
+        try:
+            return open(STAMP).read().strip() != source_hash()
+        except OSError:
+            return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
@@ -101,12 +112,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
+        if verbose:
+            print(f"liblrt_hip.so is up to date (sources {source_hash()}): not recompiled (LRT_FORCE_BUILD=1 / --force compiles anyway)", flush=True)
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-munsafe-fp-atomics", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 
