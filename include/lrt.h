@@ -155,10 +155,13 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
  * The ones a caller may want: fwd_mode (2 collect & resolve [default], 0 K-buffer packets); bwd_mode (3 bucketed replay [default],
  * 2 sorted replay, 1 replay + atomics, 0 re-trace like backward.cu:513); defer_colour; hit_cap (composited hits recorded per ray, 256);
  * spec_bwd; defer_errors; refine_ties (1: hits closer than 2 ulp are ordered by their fp64 distance); lag_bounds (1: Morton box of
- * the previous build); root_nodes (32); slab0_mm (first depth slab, 100000); the full list is lrt_set_option in lrt_kernels.hip. */
+ * the previous build); root_nodes (32); slab0_mm (first depth slab, 100000); c4_waves (waves per 16-ray tile of the forward: 0 = by the
+ * number of tiles [default: 16 up to 1536 tiles, 8 up to 3072 or for heavy tiles, else 4], or 4 / 8 / 16); wg4_per_cu (resident 4-wave
+ * workgroups per CU, 5); the full list is lrt_set_option in lrt_kernels.hip. */
 int lrt_set_option(lrt_state* st, const char* name, int value);
 /* Current value of an option (hit_cap, hit_cap_auto, fwd_mode, bwd_mode, reduce_mode, defer_colour, c4_waves): hit_cap can grow
- * by itself, see lrt_kernels.hip. */
+ * by itself, see lrt_kernels.hip.  Two read-only names: "cull_last" (primitives the last culled build kept) and "near_rays_last" (rays the
+ * last forward replayed through the reference's K-buffer because a quad lies closer than 0.2 m to their origin; waits for the device). */
 int lrt_get_option(lrt_state* st, const char* name, int* value);
 
 /* Sparse gradient exchange of the azimuth-sharded backward (lidar_rt_amd/parallel.py; not in the reference, which is

@@ -645,6 +645,34 @@ def test_randomised_scenes_cr4_against_the_legacy_packet_kernel(seed):
         assert rel_l2(a["grads"][k], b["grads"][k]) < 5e-3 and frac_outside(a["grads"][k], b["grads"][k], 1e-3) <= 2e-2, k
 
 
+@pytest.mark.parametrize("case", ["rolling_shutter_origins", "scattered_directions", "mixed"])
+def test_tiles_without_a_ray_pyramid_take_the_per_ray_path(case):
+    """Round 5: the forward culls quads and child boxes against the PYRAMID of a tile's 16 rays -- which exists only when they share one origin
+    and lie in a cone.  Rays with origins of their own (a rolling-shutter sweep: the sensor moves from column to column) and rays whose
+    directions are scattered over the sphere inside one tile must take the per-ray tests of round 4 and give the oracle's image and gradients."""
+    sc = scenes.make_scene(6000, seed=21, radius_scale=0.25)
+    H, W = 8, 96
+    o, d = scenes.kitti_rays(H, W)
+    o = o.copy(); d = d.copy()
+    r = np.random.default_rng(5)
+    if case in ("rolling_shutter_origins", "mixed"):
+        o = o + (np.arange(W, dtype=np.float32)[None, :, None] * np.array([0.004, -0.002, 0.0005], np.float32)[None, None, :])    # 0.4 m over the sweep
+    if case in ("scattered_directions", "mixed"):
+        flat = d.reshape(-1, 3); perm = r.permutation(len(flat))
+        d = flat[perm].reshape(H, W, 3).copy()                                 # every 16-ray tile now looks in 16 unrelated directions
+        if case == "mixed":
+            o = o.reshape(-1, 3)[perm].reshape(H, W, 3).copy()
+    dL = scenes.upstream_grad(H, W, seed=3)
+    fw, bw = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 0, "bwd_mode": 0})
+    assert frac_outside(a["out"], fw["out"], 1e-4) <= 2e-3 and rel_l2(a["out"], fw["out"]) < 2e-4, case
+    assert rel_l2(a["out"], b["out"]) < 5e-4, case                             # the independent K-buffer packet kernel
+    assert rel_l2(a["accum"], fw["accum"]) < 2e-3
+    for k in GRADS:
+        assert rel_l2(a["grads"][k].reshape(bw[k].shape), bw[k]) < 5e-3 and frac_outside(a["grads"][k].reshape(bw[k].shape), bw[k], 1e-3) <= 2e-2, (case, k)
+
+
 def test_backward_twice_through_one_forward(s10k):
     """retain_graph: the second backward finds the recorded colours overwritten by the first one and must recompute
     them without changing the result."""
