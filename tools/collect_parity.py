@@ -31,9 +31,11 @@ def _fmt(b):
     k, v = b; fl = v.get("floor", {})
     return (f"{k.split('.', 1)[1]}: frac {v['frac_gt_tol']:.1e} (floor {fl.get('frac_gt_tol', float('nan')):.1e}), "
             f"L2 {v['rel_l2']:.1e} (floor {fl.get('rel_l2', float('nan')):.1e}), p99 {v['p99_rel']:.1e}")
-md = ["| scene | rays | Gaussians | worst output channel (tol 1e-4) | worst gradient (tol 1e-3) | bound |", "|---|---|---:|---|---|---|"]
+md = ["| scene | rays | Gaussians | worst output channel (tol 1e-4) | worst gradient (tol 1e-3) | bound (a): against the fp32 oracle | bound (b): arbitrated by the fp64 oracle; measured worst ratios (fraction / L2) |", "|---|---|---:|---|---|---|---|"]
 for r in reps:
     md.append(f"| {r['name']} | {'x'.join(map(str, r['rays']))} | {r['gaussians']} | {_fmt(_worst(r['rows'], 'out'))} | {_fmt(_worst(r['rows'], 'grad'))} | "
-              + (f"asserted: frac <= {r['k_frac']:g} x floor, L2 <= {r['k_l2']:g} x floor" if r["asserted"] else "recorded, not asserted against the floor") + " |")
+              + (f"asserted: frac <= {r['k_frac']:g} x floor, L2 <= {r['k_l2']:g} x floor" if r["asserted"] else "recorded, not asserted against the floor") + " | "
+              + ((f"asserted: HIP-vs-fp64 frac <= {r['f64_k_frac']:g} x (fp32-vs-fp64) + counting noise, L2 <= {r['f64_k_l2']:g} x" if r["asserted"] and r.get("f64_k_frac") else "recorded")
+                 + (f"; measured {r['f64_gate_worst']['frac_ratio']:.2f} / " + (f"{r['f64_gate_worst']['l2_ratio']:.2f}" if r['f64_gate_worst'].get('l2_ratio') is not None else "-") if r.get("f64_gate_worst") else "")) + " |")
 open(os.path.join(REPO, "profiles", f"{tag}_parity.md"), "w").write(
     f"# Parity digest `{tag}` (HIP path against the fp32 oracle; floor = fp32 oracle against fp64 oracle; full table: {tag}_parity.json)\n\n" + "\n".join(md) + "\n")
