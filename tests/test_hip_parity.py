@@ -462,6 +462,21 @@ def test_hit_record_grows_after_an_overflow(s10k):
     tr.optix_context.set_option("hit_cap", 256)
 
 
+def test_dense_translucent_scene_with_4_8_and_16_waves_per_tile():
+    """every wave count of the trace kernel on the scene that found the round-3 spill fault (hundreds of candidates per ray,
+    list and queue overflows, dozens of slabs with done rays, the per-ray node tests after a queue overflow): same image and same gradients
+    whatever the number of waves per tile, and the oracle's image."""
+    sc, o, d = scenes.dense_translucent()
+    dL = scenes.upstream_grad(4, 48, seed=2)
+    fw, _ = oracle_run(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    res = {nw: run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"c4_waves": nw}) for nw in (4, 8, 16)}
+    for nw in (8, 16):
+        assert rel_l2(res[nw]["out"], res[4]["out"]) < 1e-6, nw
+        for k in GRADS:
+            assert rel_l2(res[nw]["grads"][k], res[4]["grads"][k]) < 1e-4, (nw, k)
+    assert frac_outside(res[4]["out"], fw["out"], 1e-3) <= 1e-2                 # (the knife-edge rays of this scene are examined by the test below)
+
+
 def test_dense_translucent_scene_overflows_every_capacity_once():
     """Many large Gaussians of opacity 0.03: ~130 candidates and ~100 composited hits per ray on average, up to ~600 / ~500.  The
     per-slab candidate lists (256) overflow and the slabs are halved; frame 0 exceeds the hit record (256 per ray): its backward
@@ -606,7 +621,7 @@ def test_coincident_gaussians_are_ordered_by_index():
             ref[i, 0:3] += wi * sh_colour(sc["shs"][gi], dd, 3); ref[i, 3] += wi * ti; ref[i, 4] += wi
         ref[i, 0:3] += T * scenes.BG_DEFAULT; ref[i, 8] = T
     assert (ref[:, 4] > 0.05).sum() > 12                                       # most sampled rays composite coincident pairs
-    for nw in (4, 8):
+    for nw in (4, 8, 16):
         a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw})
         b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw, "slab0_mm": 3000})
         assert rel_l2(a["out"], b["out"]) < 1e-6, nw                           # other slabs, other collection order: same image
