@@ -1682,7 +1682,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             // 8-wave groups: half as many; the non-deferred and the statistics instantiations are compiled for 2 (4-wave) / 1 (8-wave) per CU
             int per_cu = nw == 16 ? 1 : nw == 8 ? 2 : st->wg4_per_cu;
             if (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr) per_cu = min(per_cu, nw == 4 ? 2 : 1);
-            if (nw == 16 && tp.c4_qlimit >= (unsigned)C4_NQ) tp.c4_qlimit = (unsigned)C4_NQ_OF(16);      // the 16-wave instantiation's rings hold 4096 entries
+            if (nw >= 8 && tp.c4_qlimit >= (unsigned)C4_NQ) tp.c4_qlimit = (unsigned)C4_NQ_OF(8);       // the 8- and 16-wave instantiations' rings hold 4096 entries
             if (wg4 && tp.c4_qlimit < 64u * (unsigned)nw + 8u) tp.c4_qlimit = 64u * (unsigned)nw + 8u;   // room for one round's appends
             const int max_blocks = wg4 ? 256 * per_cu : 256 * 16;
             int blocks = tp.n_tiles < max_blocks ? tp.n_tiles : max_blocks;
