@@ -34,6 +34,15 @@ def test_every_cr4_instantiation_is_free_of_vector_spills_and_scratch(table):
     assert cr4["k_fwd_cr4<true, 16, false>"]["workgroups_per_cu"] == 1
 
 
+def test_the_backward_reduction_keeps_its_five_workgroups_without_spilling(table):
+    """Not a correctness gate (k_bwd_reduce4 reads no register across lanes after a divergent region) but a measured cliff: capped at 96
+    registers for five workgroups per CU, a harmless-looking edit made the compiler spill 25 VGPRs and the backward went 0.353 -> 0.410 ms
+    (profiles/r05_experiments.md)."""
+    r = table["k_bwd_reduce4"]
+    assert r["vgpr"] + r["agpr"] <= 96 and r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0, r
+    assert r["workgroups_per_cu"] == 5
+
+
 def test_gate_fails_on_a_spilling_kernel(table):
     fake = dict(table)
     fake["k_fwd_cr4<true, 16, false>"] = {**table["k_fwd_cr4<true, 4, false>"], "vgpr_spill": 15, "scratch_bytes": 64}
