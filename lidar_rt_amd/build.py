@@ -31,6 +31,10 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+# -fno-slp-vectorize (round 5): the SLP vectoriser turns the kernels' scalar float chains into v_pk_* pairs and pays for it in register moves
+# and pressure -- k_bwd_reduce4 needs 94 VGPRs with it and 69 without (5 -> 7 workgroups per CU), k_fwd_colour 126 -> 110, the build's
+# record kernels lose 4 us; k_fwd_cr4 (explicit two-wide types where they pay) is unchanged.  tools/ab_build.sh and tools/kres.sh use the same flags.
+CODEGEN_FLAGS = ["-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 STAMP = os.path.join(CSRC, "liblrt_hip.srchash")       # the hash of the sources the in-tree library was compiled from (travels with it; git-ignored)
 
 
@@ -56,6 +60,7 @@ def source_hash() -> str:
     for f in sorted(SOURCES + HEADERS):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode()); h.update(fh.read())
+    h.update(" ".join(CODEGEN_FLAGS).encode())            # the same sources under other code-generation flags are another library
     return h.hexdigest()[:16]
 
 
@@ -115,8 +120,8 @@ def _build_lib(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(f"liblrt_hip.so is up to date (sources {source_hash()}): not recompiled (LRT_FORCE_BUILD=1 / --force compiles anyway)", flush=True)
         return LIB
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-munsafe-fp-atomics", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}"] + CODEGEN_FLAGS + ["-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB] \
+        + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

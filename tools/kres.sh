@@ -5,7 +5,7 @@ set -e
 pat=$1; shift
 cd "$(dirname "$0")/../lidar_rt_amd/csrc"
 out=$(mktemp /tmp/kres.XXXXXX.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Wno-unused-value --cuda-device-only --no-gpu-bundle-output -c "$@" -o $out lrt_kernels.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-value --cuda-device-only --no-gpu-bundle-output -c "$@" -o $out lrt_kernels.hip
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $out | python3 -c "
 import re,sys,subprocess
 txt=sys.stdin.read()
