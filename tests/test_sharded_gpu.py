@@ -145,7 +145,7 @@ def test_sharded_training_steps_on_one_gpu_match_the_single_rank_run(tmp_path):
         a, b = r0[k].astype(np.float64), one[k].astype(np.float64)
         scale = max(np.abs(b).max(), 1.0)
         assert (np.abs(a - b) > 1e-5 * scale).mean() < 2e-3, (k, float(np.abs(a - b).max()))
-        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-4, k
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3, k        # (see same_run below: a handful of Adam-amplified elements)
 
 
 def test_an_undersized_culled_build_never_reaches_the_optimizer(tmp_path):
@@ -172,7 +172,9 @@ def test_an_undersized_culled_build_never_reaches_the_optimizer(tmp_path):
         np.testing.assert_array_equal(a["log"][:, 1:], b["log"][:, 1:])                           # same P, same clone / split / prune counts
         for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
             x, y = a[k].astype(np.float64), b[k].astype(np.float64)
-            assert (np.abs(x - y) > 1e-5 * max(np.abs(y).max(), 1.0)).mean() < 2e-3 and np.linalg.norm(x - y) / np.linalg.norm(y) < 1e-4, k
+            # (a handful of elements may differ by a few learning rates: Adam turns a rounding-level sign change of a near-zero gradient into
+            # a full step -- seen: 6 of 28,357 opacities apart by ~0.03, relative L2 2e-4; a step taken on an incomplete gradient moves thousands)
+            assert (np.abs(x - y) > 1e-5 * max(np.abs(y).max(), 1.0)).mean() < 2e-3 and np.linalg.norm(x - y) / np.linalg.norm(y) < 1e-3, k
     same_run(runs["once"][0], runs["clean"][0])                                                   # the redone step left no trace
     same_run(runs["always"][0], runs["clean"][0])                                                 # ... nor did the refused one
 
