@@ -212,7 +212,10 @@ def test_culled_builds_survive_ray_sets_whose_kept_count_changes_severalfold():
             kept[k] = tr.backend.state.built_count(dev)
             assert torch.equal(out, ref[k][0]), (rep, k)
             for n in ("means", "shs", "opacities"):
-                assert torch.allclose(gr[n], ref[k][1][n], rtol=1e-5, atol=1e-7 * float(ref[k][1][n].abs().max())), (rep, k, n)
+                # a Gaussian's per-hit terms are summed in the arrival order of the bucket sort's LDS atomics: signed float32 terms in another order
+                # (a few ulp of the LARGEST term, not of the sum).  A lost primitive changes its Gaussians' gradients by O(1) of their size.
+                a_, b_ = gr[n], ref[k][1][n]
+                assert torch.allclose(a_, b_, rtol=1e-4, atol=2e-6 * float(b_.abs().max())), (rep, k, n, float((a_ - b_).abs().max()), float(b_.abs().max()))
     tr.forward(rays["narrow"][0], rays["narrow"][1], *args, cull_key="narrow")     # the check of the last wide step happens here
     assert kept["wide"] > 3 * kept["narrow"], kept
     assert tr.cull_readbacks == 2, tr.cull_readbacks
