@@ -167,6 +167,7 @@ def main():
                     help="(default on one GPU) time the other --via path too, same window length, and report it beside `value` as `drop_in_path` / `direct_path`")
     ap.add_argument("--no-both-paths", dest="both_paths", action="store_false", help="time only the --via path")
     ap.add_argument("--no-vary", dest="vary", action="store_false", help="skip the `value_varying` window")
+    ap.add_argument("--no-deferred", action="store_true", help="skip the `value_deferred_accum` window (the training configuration: hit weights written by the backward)")
     ap.add_argument("--pose-inside", action="store_true", help="--vary poses 0.1 m from clutter instead of inside the scene's empty cylinder: hundreds of rays start closer than "
                     "0.2 m to a quad and take the literal K-buffer replay (k_fwd_near); reported as `value_varying.near_rays_per_frame` / `near_us`")
     ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no torch.distributed environment: print the launch command as JSON and exit (tests)")
@@ -367,6 +368,39 @@ def main():
         for _ in range(steps_long):
             ostep()
         barrier(); other = H * W * steps_long / (time.perf_counter() - t1)
+
+    # ---------------- the training configuration of the step: deferred hit weights (Tracer(deferred_accum=True) / renderer.deferred_accum):
+    # the forward issues no float atomic per composited hit, the backward's Gaussian-ordered reduction writes the same sums (train.py reads
+    # them after loss.backward() only: :156, :219).  NOT the headline: `value` keeps the reference's contract (weights complete at the forward)
+    deferred = None
+    if world == 1 and not args.no_deferred:
+        tr_d = ShardedTracer(exchange=args.exchange, deferred_accum=True)
+        for kv in args.opt:
+            k_, v_ = kv.split("="); tr_d.backend.state.set_option(k_, int(v_))
+        tr_d.backend.state.set_option("timing_every", max(1, args.time_every))
+
+        def step_deferred():
+            out_, _ = tr_d.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step, cull_key="bench-frame")
+            return out_, tr_d.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
+        if args.no_build_in_step:
+            tr_d.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
+        for _ in range(max(args.warmup, 3)):
+            step_deferred()
+        tr_d.backend.state.enable_timing(True)
+        barrier(); td = time.perf_counter()
+        for _ in range(steps_long):
+            out_d, g_d = step_deferred()
+        barrier(); el_d = time.perf_counter() - td
+        ktd = tr_d.backend.state.get_timing(dev); tr_d.backend.state.enable_timing(False)
+        tr_d.backend.state.check(dev, wait=True)
+        out_x, g_x = step()
+        torch.cuda.synchronize()
+        acc_err = float((g_d["accum"].double() - g_x["accum"].double()).norm() / g_x["accum"].double().norm().clamp_min(1e-300))
+        deferred = {"value": H * W * steps_long / el_d, "unit": "rays/s", "steps": steps_long, "ms_per_step": 1e3 * el_d / steps_long,
+                    "phase_ms": {k_: ktd[k_][0] / max(ktd[k_][1], 1) for k_ in ("build", "fwd", "bwd")},
+                    "accum_rel_l2_vs_forward_atomics": acc_err, "image_identical": bool(torch.equal(out_d, out_x)),
+                    "note": "library option deferred_accum=1 (lrt_backward_accum): no accum atomics in the forward, k_bwd_reduce4 writes the column"}
+        del tr_d
 
     # ---------------- the same step on a frame that changes every iteration (--vary)
     varying = None
@@ -573,6 +607,8 @@ def main():
             res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_long}
         if varying is not None:
             res["value_varying"] = varying
+        if deferred is not None:
+            res["value_deferred_accum"] = deferred
         if args.check_sum:
             res["checksums"] = cks
         if world == 1 and not args.no_cpu_baseline:

@@ -45,8 +45,12 @@ typedef struct lrt_state lrt_state;
 #define LRT_ERR_STATE (-3)
 
 /* ABI version of this header (bumped on any signature change); lrt_abi_version() is what the loaded library was built from. */
-#define LRT_ABI_VERSION 3
+#define LRT_ABI_VERSION 4
 int lrt_abi_version(void);
+/* 1: this is the cross-check library (compiled with -DLRT_LEGACY: liblrt_hip_legacy.so, tests only), which also carries the kernel
+ * generations that lost their measurements -- bwd_mode 1 / 2, colours inside the trace kernel (defer_colour = 0), the level-by-level tree
+ * build (fused_tree = 0 / 2).  0: the product library; lrt_set_option refuses those values with LRT_ERR_STATE. */
+int lrt_has_legacy(void);
 
 /* Text of the last error on the calling thread ("" if none). */
 const char* lrt_last_error(void);
@@ -119,6 +123,19 @@ int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* r
                  const float* dL_dout9, float* d_means, float* d_shs, float* d_opacities, float* d_scales,
                  float* d_rotations, void* stream);
 
+/* lrt_backward that also completes the forward's `accum` output (option "deferred_accum" = 1).  With that option a forward with
+ * training != 0 leaves `accum` ALL-ZERO instead of adding every composited hit's weight to it with a float atomic (forward.cu:268:
+ * 3.9 M memory-side atomics per frame at 1 M Gaussians / 64 x 2048 rays), and the backward of that forward -- which walks the same hits
+ * in Gaussian order anyway -- stores the sums into `accum_out` (P floats; every element is written, or, with "grads_prezeroed", only the
+ * touched ones).  The reference's training loop reads the weights after loss.backward() (train.py:156,219).  accum_out == NULL: plain
+ * lrt_backward.  lrt_backward itself passes the accum pointer of the most recent training forward while no other forward has run on the
+ * state since; forwards with training == 0 are never deferred. */
+int lrt_backward_accum(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M,
+                       int sh_degree, const float* means, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* background, const float* out9,
+                       const float* dL_dout9, float* d_means, float* d_shs, float* d_opacities, float* d_scales,
+                       float* d_rotations, float* accum_out, void* stream);
+
 /* Serial number of the most recent lrt_forward on this state.  The composited-hit record that the replay backward
  * uses belongs to THAT forward: a caller that runs several forwards before a backward compares the serial it saved
  * and, on mismatch, sets option "invalidate_record" so that lrt_backward re-traces instead. */
@@ -164,42 +181,13 @@ int lrt_set_option(lrt_state* st, const char* name, int value);
  * last forward replayed through the reference's K-buffer because a quad lies closer than 0.2 m to their origin; waits for the device). */
 int lrt_get_option(lrt_state* st, const char* name, int* value);
 
-/* Sparse gradient exchange of the azimuth-sharded backward (lidar_rt_amd/parallel.py; not in the reference, which is
- * single-GPU).  Row r of `rows` (n x (11 + 3M) floats) holds, for Gaussian idx[r]:
- *   [d_means 3 | d_scales 2 | d_rotations 4 | d_opacities 1 | d_shs 3M | accum 1].
- * lrt_grad_gather packs the rows of the listed Gaussians; lrt_grad_scatter_add adds rows into the dense tensors (indices
- * must be unique within one call: plain read-modify-write, so that calling it once per rank in rank order gives
- * bit-identical sums on every replica). */
-int lrt_grad_gather(int device, int P, int M, int n, const int32_t* idx, const float* d_means, const float* d_scales,
-                    const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum,
-                    float* rows, void* stream);
-int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, const float* rows, float* d_means,
-                         float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
-
-/* Owner-based exchange of the azimuth-sharded backward (not in the reference): every Gaussian has ONE owning rank -- the rank whose
- * slab axis (mean ray direction, `axes` (N,3), unit vectors) is closest to the direction sensor `origin` -> Gaussian -- and a rank's
- * partial gradient rows travel to the owner only (padded all-to-all, `cap` rows per (source, owner) pair), instead of every rank
- * receiving every row.
- *   lrt_owner_by_direction        owner[g] (int32) for all P Gaussians; the same on every rank (replicated inputs)
- *   lrt_grad_pack_foreign         cnt[N] (zeroed here; keeps counting beyond cap), idx (N, cap), rows (N, cap, 11 + 3M) of the Gaussians
- *                                 this rank touched (accum > 0) and does not own; row layout of lrt_grad_gather
- *   lrt_grad_scatter_add_counted  add one received list (count on the device, at most cap rows) into the dense tensors
- *   lrt_status_to_device          this state's error bits (last forward | sticky) as one float at a device address
- * Gathering (replicated) exchange: every rank sends the rows of ALL Gaussians it touched to every rank (one all-gather) and all
- * ranks add the lists in rank order, so that the replicas end with bit-identical sums.
- *   lrt_grad_pack_touched         cnt[1] (zeroed here; keeps counting beyond cap), idx (cap), rows (cap, 11 + 3M) of the touched Gaussians
- *   lrt_grad_zero_rows_counted    zero the rows of one list in the dense tensors (a rank clears what it wrote itself before the adds) */
-int lrt_owner_by_direction(int device, int P, const float* means, const float* origin, int N, const float* axes, int32_t* owner, void* stream);
-int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, const int32_t* owner, const float* d_means, const float* d_scales,
-                          const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx,
-                          unsigned* cnt, float* rows, void* stream);
-int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, const float* rows, float* d_means,
-                                 float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
+/* Gradient exchange of the azimuth-sharded backward (lidar_rt_amd/parallel.py; not in the reference, which is single-GPU).  A row
+ * (11 + 3M floats) holds, for one Gaussian:  [d_means 3 | d_scales 2 | d_rotations 4 | d_opacities 1 | d_shs 3M | accum 1].
+ * (ABI 4 removed the device helpers of the round-2/3 exchanges -- lrt_grad_gather, lrt_grad_scatter_add, lrt_owner_by_direction,
+ * lrt_grad_pack_foreign, lrt_grad_scatter_add_counted, lrt_grad_pack_touched, lrt_grad_zero_rows_counted: the non-default "owner" and
+ * host-verified exchanges run on torch's index_select / index_add_; the training exchange is lrt_xchg_pack / lrt_xchg_apply below.)
+ *   lrt_status_to_device          this state's error bits (last forward | sticky) as one float at a device address */
 int lrt_status_to_device(lrt_state* st, float* dst, void* stream);
-int lrt_grad_pack_touched(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations,
-                          const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx, unsigned* cnt, float* rows, void* stream);
-int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, float* d_means, float* d_scales,
-                               float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream);
 
 /* Gathering exchange without a host read and with ONE launch per side (round 4; the training exchange of lidar_rt_amd/parallel.py).
  * The Gaussian indices are cut into B = ceil(P / 1024) blocks; a message of lrt_xchg_msg_words(P, M, cap, with_rows) int32 words is

@@ -13,9 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_HIP_LIB") or os.path.join(HERE, "csrc", "liblrt_hip.so")   # env override: A/B builds
 
 EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lrt_build", "lrt_build_for_rays", "lrt_build_for_slab", "lrt_forward",
-           "lrt_refit", "lrt_backward", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_grad_gather", "lrt_grad_scatter_add",
-           "lrt_owner_by_direction", "lrt_grad_pack_foreign", "lrt_grad_scatter_add_counted", "lrt_status_to_device",
-           "lrt_grad_pack_touched", "lrt_grad_zero_rows_counted", "lrt_xchg_msg_words", "lrt_xchg_pack", "lrt_xchg_apply",
+           "lrt_refit", "lrt_backward", "lrt_backward_accum", "lrt_enable_stats", "lrt_get_stats", "lrt_set_option", "lrt_get_option", "lrt_debug_read", "lrt_enable_timing", "lrt_get_timing", "lrt_forward_serial", "lrt_built_count", "lrt_check_forward", "lrt_has_legacy",
+           "lrt_status_to_device", "lrt_xchg_msg_words", "lrt_xchg_pack", "lrt_xchg_apply",
            # include/lrt_chamfer.h
            "lrt_chamfer_create", "lrt_chamfer_destroy", "lrt_chamfer_forward", "lrt_chamfer_backward",
            "lrt_chamfer_set_option",
@@ -24,7 +23,7 @@ EXPORTS = ("lrt_abi_version", "lrt_last_error", "lrt_create", "lrt_destroy", "lr
            # include/lrt_preprocess.h
            "lrt_preprocess_forward", "lrt_preprocess_backward")
 
-ABI_VERSION = 3          # LRT_ABI_VERSION of include/lrt.h this binding was written against
+ABI_VERSION = 4          # LRT_ABI_VERSION of include/lrt.h this binding was written against
 
 _lib = None
 
@@ -45,6 +44,7 @@ def load():
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.lrt_abi_version.restype = ci
+    lib.lrt_has_legacy.restype = ci
     lib.lrt_last_error.restype = C.c_char_p
     lib.lrt_create.restype = vp; lib.lrt_create.argtypes = [ci]
     lib.lrt_destroy.restype = None; lib.lrt_destroy.argtypes = [vp]
@@ -61,6 +61,9 @@ def load():
     lib.lrt_backward.restype = ci
     lib.lrt_backward.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp]
+    lib.lrt_backward_accum.restype = ci
+    lib.lrt_backward_accum.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, vp]
     lib.lrt_enable_stats.restype = ci; lib.lrt_enable_stats.argtypes = [vp, ci]
     lib.lrt_get_stats.restype = ci; lib.lrt_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     lib.lrt_enable_timing.restype = ci; lib.lrt_enable_timing.argtypes = [vp, ci]
@@ -68,14 +71,7 @@ def load():
     lib.lrt_forward_serial.restype = C.c_longlong; lib.lrt_forward_serial.argtypes = [vp]
     lib.lrt_built_count.restype = ci; lib.lrt_built_count.argtypes = [vp]
     lib.lrt_check_forward.restype = ci; lib.lrt_check_forward.argtypes = [vp, ci]
-    lib.lrt_grad_gather.restype = ci; lib.lrt_grad_gather.argtypes = [ci, ci, ci, ci] + [vp] * 9
-    lib.lrt_grad_scatter_add.restype = ci; lib.lrt_grad_scatter_add.argtypes = [ci, ci, ci, ci] + [vp] * 9
-    lib.lrt_owner_by_direction.restype = ci; lib.lrt_owner_by_direction.argtypes = [ci, ci, vp, vp, ci, vp, vp, vp]
-    lib.lrt_grad_pack_foreign.restype = ci; lib.lrt_grad_pack_foreign.argtypes = [ci, ci, ci, ci, ci, ci] + [vp] * 11
-    lib.lrt_grad_scatter_add_counted.restype = ci; lib.lrt_grad_scatter_add_counted.argtypes = [ci, ci, ci, ci] + [vp] * 10
     lib.lrt_status_to_device.restype = ci; lib.lrt_status_to_device.argtypes = [vp, vp, vp]
-    lib.lrt_grad_pack_touched.restype = ci; lib.lrt_grad_pack_touched.argtypes = [ci, ci, ci, ci] + [vp] * 10
-    lib.lrt_grad_zero_rows_counted.restype = ci; lib.lrt_grad_zero_rows_counted.argtypes = [ci, ci, ci, ci] + [vp] * 9
     lib.lrt_xchg_msg_words.restype = C.c_longlong; lib.lrt_xchg_msg_words.argtypes = [ci, ci, ci, ci]
     lib.lrt_xchg_pack.restype = ci; lib.lrt_xchg_pack.argtypes = [ci, ci, ci, ci] + [vp] * 8 + [ci, ci, vp]
     lib.lrt_xchg_apply.restype = ci; lib.lrt_xchg_apply.argtypes = [ci, ci, ci, ci, ci, ci, vp, C.c_longlong] + [vp] * 7 + [ci, vp]
@@ -112,6 +108,11 @@ class _TraceCalls:
             if torch.cuda.is_available(): torch.cuda.synchronize()
             return r
         return g
+
+
+def has_legacy() -> bool:
+    """True when the loaded library is the cross-check build (-DLRT_LEGACY; env LRT_HIP_LIB points at liblrt_hip_legacy.so)."""
+    return bool(load().lrt_has_legacy())
 
 
 def check(rc: int, what: str):

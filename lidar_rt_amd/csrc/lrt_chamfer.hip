@@ -224,6 +224,7 @@ __device__ __forceinline__ void ch_leaf(const float4* __restrict__ pt, float qx,
     }
 }
 
+#ifdef LRT_LEGACY      // the lane-per-query kernel (mode 3): kept for A/B measurements in the cross-check library only
 __global__ __launch_bounds__(CH_QBLOCK) void kc_query(ChParams p, int depth)
 {
     extern __shared__ unsigned long long s_stack[];         // [depth][CH_QBLOCK]: (bound bits << 32) | entry
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(CH_QBLOCK) void kc_query(ChParams p, int depth)
     p.dist[dir][qi] = best;
     p.idx[dir][qi] = besti;
 }
+#endif  // LRT_LEGACY
 
 // ---------------------------------------------------------------------------------------------------
 // Packet search (default tree kernel): one WAVEFRONT owns 64 Morton-consecutive queries (the other cloud's sorted
@@ -623,13 +625,17 @@ static int ch_forward_one(lrt_chamfer* ch, int N, const float* xyz1, int M, cons
     p.dist[0] = dist1; p.dist[1] = dist2; p.idx[0] = idx1; p.idx[1] = idx2;
     const int n = N + M;
     const int depth = 7 * (Kmax - 1) + 1;
+#ifdef LRT_LEGACY
     if (ch->mode == 3) {                                    // lane-per-query kernel (kept for A/B measurements)
         const size_t lds = (size_t)depth * CH_QBLOCK * sizeof(unsigned long long);
         if (lds > 160 * 1024) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_forward: clouds too large for the LDS stack");
         if (lds > 64 * 1024)
             CH_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kc_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc_query, dim3((n + CH_QBLOCK - 1) / CH_QBLOCK), dim3(CH_QBLOCK), lds, stream, p, depth);
-    } else {
+    } else
+#endif
+    {
+        (void)n; (void)depth;
         rc = ch_launch_pk<false>(ch, p, Kmax, total_pts, stream);
         if (rc != LRT_OK) return rc;
     }
@@ -671,7 +677,13 @@ void lrt_chamfer_destroy(lrt_chamfer* ch)
 int lrt_chamfer_set_option(lrt_chamfer* ch, const char* name, int value)
 {
     if (!ch || !name) CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_set_option: null argument");
-    if (!strcmp(name, "mode")) { if (value < 0 || value > 3) CH_FAIL(LRT_ERR_ARG, "mode must be 0..3"); ch->mode = value; return LRT_OK; }
+    if (!strcmp(name, "mode")) {
+        if (value < 0 || value > 3) CH_FAIL(LRT_ERR_ARG, "mode must be 0..3");
+#ifndef LRT_LEGACY
+        if (value == 3) CH_FAIL(LRT_ERR_STATE, "mode 3 (the lane-per-query kernel) exists in the cross-check library only (-DLRT_LEGACY)");
+#endif
+        ch->mode = value; return LRT_OK;
+    }
     if (!strcmp(name, "brute_max_pairs_log2")) { if (value < 0 || value > 62) CH_FAIL(LRT_ERR_ARG, "brute_max_pairs_log2 out of range"); ch->brute_max_pairs_log2 = value; return LRT_OK; }
     CH_FAIL(LRT_ERR_ARG, "lrt_chamfer_set_option: unknown option '%s'", name);
 }

@@ -45,6 +45,15 @@
 // An EMPTY child slot is stored as the degenerate box [1e30,1e30]^3: a min/max slab test treats an inverted box
 // (lo > hi) as the huge box [hi, lo] and would descend into it, a far-away point is never reached (|t| >= 1e30).
 #define LRT_EMPTY 1e30f
+// -DLRT_LEGACY builds the cross-check library (lidar_rt_amd/build.py: liblrt_hip_legacy.so, tests only): the kernel generations and modes
+// that lost their measurements -- bwd_mode 1 / 2 (k_bwd_replay, k_bwd_prep, k_bwd_reduce3), colours inside the trace kernel (k_fwd_cr4<false, ..>),
+// the level-by-level tree build (k_make_records, k_level1, k_upper, k_tree_top), the round-2/3 exchange helpers -- stay available there as
+// independent implementations; the shipped library does not carry them.
+#ifdef LRT_LEGACY
+#define LRT_HAS_LEGACY 1
+#else
+#define LRT_HAS_LEGACY 0
+#endif
 
 #ifndef LRT_SORT_LO_BIT
 #define LRT_SORT_LO_BIT 31
@@ -193,6 +202,7 @@ struct lrt_state {
     int n_nodes, n_leaves;
     LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
+    int deferred_accum; float* acc_ptr; long long acc_serial; int acc_pending;   // option deferred_accum: a training forward leaves `accum` all-zero, the backward of that forward writes the per-Gaussian sums of composite weights (forward.cu:268) into it
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int timing_every; unsigned timer_calls[4];      // see ScopedTimer
     int colour_variant;  // 1 (default): four lanes per hit in k_fwd_colour when the SH table is (16, 3); 0: lane per hit (any table shape)
@@ -421,6 +431,7 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
         return alpha;
     }
     const float dL_dG = op * dLa;
+    if (p.accum) unsafeAtomicAdd(p.accum + g, wgt);         // option deferred_accum: forward.cu:268's sum, taken here (lrt_backward_accum)
     unsafeAtomicAdd(p.d_opac + g, hg.G * dLa);
     const float dNgs[3] = {dL[5] * wgt, dL[6] * wgt, dL[7] * wgt};
     LrtHitGrad gr;
@@ -446,87 +457,10 @@ __device__ __forceinline__ float bwd_hit(const TraceParams& p, const float* o, c
 #include "lrt_bucket.inc"
 
 // ---------------------------------------------------------------------------------------------------
-// Sparse gradient exchange helpers (azimuth-sharded backward): row r <-> Gaussian idx[r], see include/lrt.h.
+// Gradient exchange of the azimuth-sharded backward (include/lrt.h: lrt_xchg_*).  The device helpers of the round-2/3 exchanges ("owner",
+// the host-verified gathering exchange: lrt_grad_gather / _scatter_add / _pack_foreign / _pack_touched / ...) left the library in round 6:
+// those non-default exchanges run on torch's index_select / index_add_ (lidar_rt_amd/parallel.py).
 struct GradFields { float* f[6]; int w[6]; };               // means, scales, rotations, opacities, shs, accum
-template <bool GATHER>
-__global__ void __launch_bounds__(256) k_grad_rows(int n, int width, const int32_t* __restrict__ idx, GradFields g, float* rows)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n * width) return;
-    const int r = (int)(t / width);
-    int e = (int)(t - (long long)r * width);
-    const int gi = idx[r];
-    int k = 0;
-    while (e >= g.w[k]) { e -= g.w[k]; k++; }
-    float* p = g.f[k] + (size_t)gi * g.w[k] + e;
-    if (GATHER) rows[t] = *p; else *p += rows[t];
-}
-
-// Counted variants for the owner-based and the gathering exchange: list l of `nlists` holds cnt[l] (device) rows of at most `cap`;
-// thread = (list, row, column).  MODE 0: rows <- dense, 1: dense += rows, 2: dense rows <- 0.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_grad_rows_multi(int cap, int width, const unsigned* __restrict__ cnt, const int32_t* __restrict__ idx,
-                                                         GradFields g, float* rows, int skip_list)
-{
-    const int l = blockIdx.y;
-    if (l == skip_list) return;
-    const unsigned n = min(cnt[l], (unsigned)cap);
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n * width) return;
-    const int r = (int)(t / width);
-    int e = (int)(t - (long long)r * width);
-    const int gi = idx[(size_t)l * cap + r];
-    int k = 0;
-    while (e >= g.w[k]) { e -= g.w[k]; k++; }
-    float* p = g.f[k] + (size_t)gi * g.w[k] + e;
-    if (MODE == 2) { *p = 0.f; return; }
-    float* q = rows + ((size_t)l * cap + r) * width + (t - (long long)r * width);
-    if (MODE == 0) *q = *p; else *p += *q;
-}
-
-// Gaussians this rank touched (accum > 0), in index order inside a block and block order by the counter: at most cap are listed,
-// cnt keeps counting beyond cap so that the overflow is visible
-__global__ void __launch_bounds__(256) k_list_touched(int P, int cap, const float* __restrict__ accum, int32_t* __restrict__ idx, unsigned* __restrict__ cnt)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool t = g < P && accum[g] > 0.f;
-    const unsigned long long m = __ballot(t);
-    if (!m) return;
-    unsigned base = 0u;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(cnt, (unsigned)__popcll(m));     // one atomic per wave
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    const unsigned slot = base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-    if (t && slot < (unsigned)cap) idx[slot] = g;
-}
-
-// owner[g] = the rank whose slab axis is closest to the direction sensor -> Gaussian (ties: the lowest rank)
-__global__ void __launch_bounds__(256) k_owner(int P, const float* __restrict__ means, const float* __restrict__ origin, int N,
-                                               const float* __restrict__ axes, int32_t* __restrict__ owner)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    const float vx = means[3 * (size_t)g] - origin[0], vy = means[3 * (size_t)g + 1] - origin[1], vz = means[3 * (size_t)g + 2] - origin[2];
-    float best = -3.0e38f; int bk = 0;
-    for (int k = 0; k < N; k++) {
-        const float dp = vx * axes[3 * k] + vy * axes[3 * k + 1] + vz * axes[3 * k + 2];
-        if (dp > best) { best = dp; bk = k; }
-    }
-    owner[g] = bk;
-}
-
-// Gaussians this rank touched (accum > 0) but does not own: appended to the index list of their owner (at most cap per owner;
-// cnt keeps counting beyond cap so that the receiver and the host see the overflow)
-__global__ void __launch_bounds__(256) k_list_foreign(int P, int rank, int cap, const int32_t* __restrict__ owner, const float* __restrict__ accum,
-                                                      int32_t* __restrict__ idx, unsigned* __restrict__ cnt)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    const int d = owner[g];
-    if (d == rank || !(accum[g] > 0.f)) return;
-    const unsigned slot = atomicAdd(cnt + d, 1u);
-    if (slot < (unsigned)cap) idx[(size_t)d * cap + slot] = g;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Gathering exchange, round 4 (include/lrt.h: lrt_xchg_*): ONE launch packs a rank's touched rows, ONE launch applies all N received
 // lists -- deterministic without a host read and without one launch per list.  The Gaussian indices are cut into blocks of XB_G = 1024;
@@ -675,19 +609,11 @@ __global__ void __launch_bounds__(256) k_xchg_apply(int P, int B, int N, int ran
     }
 }
 
-__global__ void k_status_word(const unsigned* __restrict__ ctrl, float* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (float)(ctrl[10] | ctrl[12]); }
-
 #include "lrt_near.inc"
 #include "lrt_trace_legacy.inc"
 
 #include "lrt_collect.inc"
 #include "lrt_collect4.inc"
-
-__global__ void k_fill_i32(int n, int32_t v, int32_t* dst)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = v;
-}
 
 // The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
 // tree_nodes != null: the LBVH of the build in front of this forward still lacks its levels >= 4 (k_make_tree only combined the level-3
@@ -754,23 +680,38 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
     if ((size_t)total > st->cap_nodes) LRT_FAIL(LRT_ERR_STATE, "lrt_build: node capacity exceeded");
     *total_out = total; *nl_out = nl;
     finish_tree_now(st, stream);                                  // two builds in a row: `top` must be re-armed before this build combines into it
-    if (st->fused_tree && records && Pk > 0) {
+#ifdef LRT_LEGACY
+    const bool fused = st->fused_tree && records && Pk > 0;
+#else
+    const bool fused = true;      // (an empty structure too: one workgroup writes the single node with eight empty children)
+    (void)records;
+#endif
+    if (fused) {
         TreeLayout lay; memset(&lay, 0, sizeof(lay));
         lay.L = L; for (int l = 1; l <= L; l++) { lay.cnt[l] = cnt[l]; lay.off[l] = off[l]; }
         const int Ppad = (Pk + LRT_LEAF - 1) / LRT_LEAF * LRT_LEAF;
-        lrt_launch(st->lrec, k_make_tree, dim3((Ppad + MT_THREADS - 1) / MT_THREADS), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
+        const int mt_blocks = Ppad > 0 ? (Ppad + MT_THREADS - 1) / MT_THREADS : 1;
+        lrt_launch(st->lrec, k_make_tree, dim3(mt_blocks), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
                            st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top,
                            kept_ptr ? st->cone_host : (unsigned*)nullptr);
+#ifdef LRT_LEGACY
         if (st->fused_tree == 2 && L >= 4) lrt_launch(st->lrec, k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
-        else if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
+        else
+#endif
+        if (L >= 4) { st->tree_pending = 1; st->tree_lay = lay; }      // the next k_fwd_init writes the levels >= 4
         return LRT_OK;
     }
+#ifdef LRT_LEGACY
     if (records && Pk > 0)
         lrt_launch(st->lrec, k_make_records, dim3((Pk + LRT_LEAF + TB - 1) / TB), dim3(TB), 0, stream, Pk, st->vals_b, means, scales, rots, opac, mod, st->rec, st->aabb, pack, kept_ptr);
     lrt_launch(st->lrec, k_level1, dim3((cnt[1] * 8 + TB - 1) / TB), dim3(TB), 0, stream, Pk, cnt[1], off[1], st->aabb, st->nodes, st->nodes_aos);
     for (int l = 2; l <= L; l++)
         lrt_launch(st->lrec, k_upper, dim3((cnt[l] * 8 + TB - 1) / TB), dim3(TB), 0, stream, cnt[l], off[l], cnt[l - 1], off[l - 1], st->nodes, st->nodes_aos);
     return LRT_OK;
+#else
+    (void)TB;
+    return LRT_OK;
+#endif
 }
 
 static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
@@ -836,6 +777,7 @@ struct ScopedTimer {
 extern "C" {
 
 int lrt_abi_version(void) { return LRT_ABI_VERSION; }
+int lrt_has_legacy(void) { return LRT_HAS_LEGACY; }
 const char* lrt_last_error(void) { return g_err; }
 // the same buffer for the other translation units of this library (lrt_chamfer.hip); not part of the ABI
 __attribute__((visibility("hidden"))) char* lrt_internal_errbuf(void) { return g_err; }
@@ -901,7 +843,7 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
     if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
     const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
         {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec},
-        {"graph", st->graph_mode}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
+        {"graph", st->graph_mode}, {"deferred_accum", st->deferred_accum}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
     if (!strcmp(name, "cull_last")) {                        // primitives the last culled build kept (raw: also those a too small speculative size lost); -1 = none yet
         DeviceGuard dg(st->device);
@@ -954,12 +896,13 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
+    if (!strcmp(name, "deferred_accum")) { st->deferred_accum = value ? 1 : 0; st->acc_pending = 0; return LRT_OK; }   // see lrt_backward_accum
     if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
     if (!strcmp(name, "morton_extra_bits")) { if (value < 0 || value > 12) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: morton_extra_bits must be 0..12"); st->morton_extra = value; return LRT_OK; }
     if (!strcmp(name, "timing_every")) { st->timing_every = value < 1 ? 1 : value; memset(st->timer_calls, 0, sizeof(st->timer_calls)); return LRT_OK; }
     if (!strcmp(name, "colour_variant")) { st->colour_variant = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
-    if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
+    if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); if (value != 1 && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_tree=%d (the level-by-level / two-launch build) exists in the cross-check library only (-DLRT_LEGACY)", value); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
@@ -971,11 +914,12 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         st->tile16_w_log2 = l2; return LRT_OK;
     }
     if (!strcmp(name, "slab0_mm")) { if (value < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: slab0_mm must be positive"); st->slab0 = 1e-3f * (float)value; return LRT_OK; }
-    if (!strcmp(name, "defer_colour")) { st->defer_colour = value ? 1 : 0; return LRT_OK; }
+    if (!strcmp(name, "defer_colour")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: defer_colour=0 (colours inside the trace kernel) exists in the cross-check library only (-DLRT_LEGACY)"); st->defer_colour = value ? 1 : 0; return LRT_OK; }
     if (!strcmp(name, "invalidate_record")) { st->hits_valid = 0; return LRT_OK; }   // next backward re-traces
     if (!strcmp(name, "reduce_mode")) { if (value != 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: reduce_mode 0 and 1 were retired (k_bwd_reduce3 = mode 2 is the reduction)"); return LRT_OK; }
     if (!strcmp(name, "bwd_mode")) {           // 0 re-trace + atomics, 1 replay + atomics, 2 replay + sorted reduction, 3 replay + bucketed reduction
         if (value < 0 || value > 3) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: bwd_mode must be 0, 1, 2 or 3");
+        if ((value == 1 || value == 2) && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: bwd_mode %d (replay + atomics / sorted reduction) exists in the cross-check library only (-DLRT_LEGACY); the product has 3 (bucketed replay) and 0 (re-trace)", value);
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
     }
     if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
@@ -995,41 +939,6 @@ int lrt_built_count(lrt_state* st)
     if (!st || st->P < 0) return -1;
     if (st->cone_pending && hipEventSynchronize(st->cone_ev) == hipSuccess) return (int)(st->cone_host[0] < (unsigned)st->P_built ? st->cone_host[0] : (unsigned)st->P_built);
     return st->P_built;
-}
-
-static int grad_rows(const char* fn, bool gather, int device, int P, int M, int n, const int32_t* idx, float* rows, float* d_means,
-                     float* d_scales, float* d_rots, float* d_opac, float* d_shs, float* accum, void* stream_)
-{
-    int nd = 0;
-    if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) LRT_FAIL(LRT_ERR_ARG, "%s: no HIP device %d", fn, device);
-    if (P < 0 || M < 0 || n < 0 || n > P) LRT_FAIL(LRT_ERR_ARG, "%s: bad sizes P=%d M=%d n=%d", fn, P, M, n);
-    if (n == 0) return LRT_OK;
-    if (!idx || !rows || !d_means || !d_scales || !d_rots || !d_opac || !accum || (M > 0 && !d_shs)) LRT_FAIL(LRT_ERR_ARG, "%s: null pointer", fn);
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "%s: cannot select HIP device %d", fn, device);
-    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rots; g.w[2] = 4; g.f[3] = d_opac; g.w[3] = 1;
-    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
-    const int width = 11 + 3 * M;
-    const long long tot = (long long)n * width;
-    const int blocks = (int)((tot + 255) / 256);
-    if (gather) hipLaunchKernelGGL(k_grad_rows<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, n, width, idx, g, rows);
-    else hipLaunchKernelGGL(k_grad_rows<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, n, width, idx, g, rows);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-int lrt_grad_gather(int device, int P, int M, int n, const int32_t* idx, const float* d_means, const float* d_scales,
-                    const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum,
-                    float* rows, void* stream)
-{
-    return grad_rows("lrt_grad_gather", true, device, P, M, n, idx, rows, const_cast<float*>(d_means), const_cast<float*>(d_scales),
-                     const_cast<float*>(d_rotations), const_cast<float*>(d_opacities), const_cast<float*>(d_shs), const_cast<float*>(accum), stream);
-}
-
-int lrt_grad_scatter_add(int device, int P, int M, int n, const int32_t* idx, const float* rows, float* d_means,
-                         float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream)
-{
-    return grad_rows("lrt_grad_scatter_add", false, device, P, M, n, idx, const_cast<float*>(rows), d_means, d_scales, d_rotations,
-                     d_opacities, d_shs, accum, stream);
 }
 
 // The status block of the most recent COMPLETED forward is on the host (st->hit_ovf_host, written by k_fwd_fin): take what the
@@ -1066,93 +975,8 @@ int lrt_status_to_device(lrt_state* st, float* dst, void* stream_)
 {
     if (!st || !dst) LRT_FAIL(LRT_ERR_ARG, "lrt_status_to_device: null argument");
     DeviceGuard dg(st->device);
-    hipLaunchKernelGGL(k_status_word, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const unsigned*)st->ctrl, dst);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-int lrt_owner_by_direction(int device, int P, const float* means, const float* origin, int N, const float* axes, int32_t* owner, void* stream_)
-{
-    if (P < 0 || N < 1 || (P > 0 && (!means || !origin || !axes || !owner))) LRT_FAIL(LRT_ERR_ARG, "lrt_owner_by_direction: bad argument");
-    if (P == 0) return LRT_OK;
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_owner_by_direction: cannot select HIP device %d", device);
-    hipLaunchKernelGGL(k_owner, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, means, origin, N, axes, owner);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-/* Owner-based gradient exchange, sender side: list the touched Gaussians of other owners (cnt[N] zeroed here, idx (N, cap)), then
- * pack their rows (N, cap, 11 + 3M) -- the row layout of lrt_grad_gather.  cnt keeps counting beyond cap (overflow is visible). */
-int lrt_grad_pack_foreign(int device, int P, int M, int N, int rank, int cap, const int32_t* owner, const float* d_means, const float* d_scales,
-                          const float* d_rotations, const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx,
-                          unsigned* cnt, float* rows, void* stream_)
-{
-    if (P < 0 || M < 0 || N < 1 || rank < 0 || rank >= N || cap < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_foreign: bad sizes");
-    if (!owner || !idx || !cnt || !rows || !accum) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_foreign: null pointer");
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_pack_foreign: cannot select HIP device %d", device);
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)N * sizeof(unsigned), stream));
-    if (P == 0) return LRT_OK;
-    hipLaunchKernelGGL(k_list_foreign, dim3((P + 255) / 256), dim3(256), 0, stream, P, rank, cap, owner, accum, idx, cnt);
-    GradFields g; g.f[0] = const_cast<float*>(d_means); g.w[0] = 3; g.f[1] = const_cast<float*>(d_scales); g.w[1] = 2; g.f[2] = const_cast<float*>(d_rotations); g.w[2] = 4;
-    g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
-    const int width = 11 + 3 * M;
-    const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<0>, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, rank);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-/* Receiver side: add the rows of ONE source list (count on the device) into the dense tensors (unique indices inside a list: plain
- * read-modify-write; call once per source in rank order for a deterministic sum). */
-int lrt_grad_scatter_add_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, const float* rows, float* d_means,
-                                 float* d_scales, float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream_)
-{
-    if (P < 0 || M < 0 || cap < 1 || !cnt_dev || !idx || !rows) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_scatter_add_counted: bad argument");
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_scatter_add_counted: cannot select HIP device %d", device);
-    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rotations; g.w[2] = 4; g.f[3] = d_opacities; g.w[3] = 1;
-    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
-    const int width = 11 + 3 * M;
-    const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<1>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, const_cast<float*>(rows), -1);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-/* Gathering (replicated) exchange, sender side: list the Gaussians this rank touched (accum > 0; cnt[0] zeroed here, keeps counting
- * beyond cap) and pack their rows (cap, 11 + 3M) -- the row layout of lrt_grad_gather. */
-int lrt_grad_pack_touched(int device, int P, int M, int cap, const float* d_means, const float* d_scales, const float* d_rotations,
-                          const float* d_opacities, const float* d_shs, const float* accum, int32_t* idx, unsigned* cnt, float* rows, void* stream_)
-{
-    if (P < 0 || M < 0 || cap < 1) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_touched: bad sizes");
-    if (!idx || !cnt || !rows || (P > 0 && !accum)) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_pack_touched: null pointer");
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_pack_touched: cannot select HIP device %d", device);
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned), stream));
-    if (P == 0) return LRT_OK;
-    hipLaunchKernelGGL(k_list_touched, dim3((P + 255) / 256), dim3(256), 0, stream, P, cap, accum, idx, cnt);
-    GradFields g; g.f[0] = const_cast<float*>(d_means); g.w[0] = 3; g.f[1] = const_cast<float*>(d_scales); g.w[1] = 2; g.f[2] = const_cast<float*>(d_rotations); g.w[2] = 4;
-    g.f[3] = const_cast<float*>(d_opacities); g.w[3] = 1; g.f[4] = const_cast<float*>(d_shs); g.w[4] = 3 * M; g.f[5] = const_cast<float*>(accum); g.w[5] = 1;
-    const int width = 11 + 3 * M;
-    const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<0>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, stream, cap, width, (const unsigned*)cnt, (const int32_t*)idx, g, rows, -1);
-    HIPCHK(hipGetLastError());
-    return LRT_OK;
-}
-
-/* Zero the rows of ONE list (count on the device) in the dense tensors: the gathering exchange clears exactly what this rank wrote
- * before it adds every rank's rows in rank order (the rest of the buffers is zero already). */
-int lrt_grad_zero_rows_counted(int device, int P, int M, int cap, const unsigned* cnt_dev, const int32_t* idx, float* d_means, float* d_scales,
-                               float* d_rotations, float* d_opacities, float* d_shs, float* accum, void* stream_)
-{
-    if (P < 0 || M < 0 || cap < 1 || !cnt_dev || !idx) LRT_FAIL(LRT_ERR_ARG, "lrt_grad_zero_rows_counted: bad argument");
-    DeviceGuard dg(device); if (!dg.ok) LRT_FAIL(LRT_ERR_HIP, "lrt_grad_zero_rows_counted: cannot select HIP device %d", device);
-    GradFields g; g.f[0] = d_means; g.w[0] = 3; g.f[1] = d_scales; g.w[1] = 2; g.f[2] = d_rotations; g.w[2] = 4; g.f[3] = d_opacities; g.w[3] = 1;
-    g.f[4] = d_shs; g.w[4] = 3 * M; g.f[5] = accum; g.w[5] = 1;
-    const int width = 11 + 3 * M;
-    const long long per = (long long)cap * width;
-    hipLaunchKernelGGL(k_grad_rows_multi<2>, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream_, cap, width, cnt_dev, idx, g, (float*)nullptr, -1);
-    HIPCHK(hipGetLastError());
+    // the forward's epilogue (fwd_publish_status) left the bits as a float in ctrl[14]: a 4-byte device copy, no kernel of its own
+    HIPCHK(hipMemcpyAsync(dst, st->ctrl + 14, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return LRT_OK;
 }
 
@@ -1315,13 +1139,7 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
                 st->cone_prev = st->cone_host[0]; st->cone_seen = 1;
             }
-            if (n_rays <= 131072) lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W);
-            else {
-                int rb = (n_rays + TB - 1) / TB; if (rb > 256) rb = 256;
-                lrt_launch(st->lrec, k_cone_init, dim3(1), dim3(64), 0, stream, cone);
-                lrt_launch(st->lrec, k_cone_axis, dim3(rb), dim3(TB), 0, stream, n_rays, ray_o, ray_d, cone);
-                lrt_launch(st->lrec, k_cone_angle, dim3(rb), dim3(TB), 0, stream, n_rays, ray_d, cone);
-            }
+            lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W);      // one workgroup for any ray set (round 6: the three-launch path for > 131072 rays is gone)
         }
         // three bounds sets rotate: this build READS set s (the box of the previous build's centres -- or, on the first build of a state
         // and with option lag_bounds=0, the box k_bounds computes now), ACCUMULATES its own frame's box into set s+1 and ARMS set s+2
@@ -1601,6 +1419,11 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
     tp.ray_o = ray_o; tp.ray_d = ray_d; tp.shs = shs; tp.bg = bg; tp.out9 = out9; tp.accum = accum; tp.mod = st->mod;
     st->hits_valid = 0; st->fast_valid = 0;
     st->fwd_serial++;
+    // option deferred_accum (training loops, train.py:156,219 read the weights only after loss.backward()): the forward leaves `accum` at the
+    // zeros k_fwd_init wrote -- no float atomic per composited hit (3.94 M memory-side atomics per S1M frame) -- and the backward of THIS
+    // forward stores the same sums from its Gaussian-ordered records (lrt_backward_accum).  Forwards without `training` stay exact at once.
+    st->acc_pending = 0;
+    if (st->deferred_accum && training && P > 0 && (size_t)H * W > 0) { tp.accum = nullptr; st->acc_ptr = accum; st->acc_serial = st->fwd_serial; st->acc_pending = 1; }
     const size_t HW = (size_t)H * W;
     if (HW > st->near_cap) {
         HIPCHK(hipStreamSynchronize(stream));
@@ -1627,16 +1450,18 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             HIPCHK(hipMalloc(&st->hit_pk, nrec * sizeof(float4)));
             HIPCHK(hipMalloc(&st->ray_pk, HW * 4 * sizeof(float4)));
             HIPCHK(hipMalloc(&st->hit_n, HW * sizeof(int)));
+            const size_t kc = HW * (size_t)(st->hit_cap < st->key_avg ? st->hit_cap : st->key_avg);     // hits of a frame the backward's record buffers hold: 64 per ray on average to start with
+#ifdef LRT_LEGACY      // the sorted backward's key lists and scan / sort workspaces (bwd_mode 2)
             HIPCHK(hipMalloc(&st->hit_off, (HW + 1) * sizeof(unsigned)));
             { size_t sb = 0; HIPCHK(rocprim::exclusive_scan(nullptr, sb, (unsigned*)st->hit_n, st->hit_off, 0u, HW, rocprim::plus<unsigned>(), stream));
               st->scan_tmp_bytes = sb + 256; HIPCHK(hipMalloc(&st->scan_tmp, st->scan_tmp_bytes)); }
-            const size_t kc = HW * (size_t)(st->hit_cap < st->key_avg ? st->hit_cap : st->key_avg);     // dense key list: 64 hits/ray on average to start with
             HIPCHK(hipMalloc(&st->hit_keys, kc * sizeof(unsigned long long)));
             HIPCHK(hipMalloc(&st->hit_keys_sorted, kc * sizeof(unsigned long long)));
             size_t tmpb = 0;
             HIPCHK(rocprim::radix_sort_keys<lrt_build_sort_cfg>(nullptr, tmpb, st->hit_keys, st->hit_keys_sorted, kc, 0, 64, stream));
             st->bsort_tmp_bytes = tmpb + 256;
             HIPCHK(hipMalloc(&st->bsort_tmp, st->bsort_tmp_bytes));
+#endif
             st->key_cap = (unsigned)(kc < 0xffffffffull ? kc : 0xffffffffull);
             st->hit_rays_cap = HW; st->hit_cap_alloc = st->hit_cap; st->key_avg_alloc = st->key_avg;
         }
@@ -1646,8 +1471,9 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         if (defer && !st->ovf_list) HIPCHK(hipMalloc(&st->ovf_list, (size_t)st->ovf_cap * sizeof(float4)));
         tp.ovf_list = st->ovf_list; tp.ovf_count = st->ovf_count; tp.ovf_cap = st->ovf_cap;
     }
-    // k_fwd_cr4 addresses the leaf records with 32-bit byte offsets: beyond 2^26 primitives the K-buffer packet kernel takes over
-    if (st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26)) {
+    // k_fwd_cr4 addresses the leaf records with 32-bit byte offsets: beyond 2^26 primitives the K-buffer packet kernel takes over; the product
+    // library has the deferred-colour instantiations only, so a forward without a hit record (no Gaussians, no rays) takes the packet kernel too
+    if (st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && (LRT_HAS_LEGACY || (defer && record))) {
         const bool wg4 = true;                                      // one workgroup of 4 (or 8) waves per 16-ray tile: k_fwd_cr4
         const int tile_rays = C4_RAYS;
         const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
@@ -1723,9 +1549,13 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 const bool sts = tp.stats != nullptr || tp.dbg != nullptr;
                 const dim3 g_(blocks), b_(64 * nw);
 #define LRT_CR4(D_, N_, S_) lrt_launch(st->lrec, (k_fwd_cr4<D_, N_, S_>), g_, b_, 0, stream, tp, rec_, naos_)
-                if (wg4 && nw == 16 && dfr && !sts) LRT_CR4(true, 16, false);      // (the statistics / non-deferred variants exist for 4 and 8 waves only)
-                else if (wg4 && nw >= 8) { if (dfr) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); } else { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); } }
-                else                { if (dfr) { if (sts) LRT_CR4(true, 4, true); else LRT_CR4(true, 4, false); } else { if (sts) LRT_CR4(false, 4, true); else LRT_CR4(false, 4, false); } }
+                if (wg4 && nw == 16 && dfr && !sts) LRT_CR4(true, 16, false);      // (the statistics variants exist for 4 and 8 waves only)
+#ifdef LRT_LEGACY      // colours inside the trace kernel (defer_colour = 0): 183-195 registers, two workgroups per CU
+                else if (!dfr && nw >= 8) { if (sts) LRT_CR4(false, 8, true); else LRT_CR4(false, 8, false); }
+                else if (!dfr)            { if (sts) LRT_CR4(false, 4, true); else LRT_CR4(false, 4, false); }
+#endif
+                else if (wg4 && nw >= 8) { if (sts) LRT_CR4(true, 8, true); else LRT_CR4(true, 8, false); }
+                else                     { if (sts) LRT_CR4(true, 4, true); else LRT_CR4(true, 4, false); }
 #undef LRT_CR4
             }
             // rays with a quad closer than 0.2 m (normally none: the launch returns at once): the reference's stale-slot rule
@@ -1766,22 +1596,33 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
 static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
                          const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
                          const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
-                         float* d_opac, float* d_scales, float* d_rots, void* stream_);
+                         float* d_opac, float* d_scales, float* d_rots, float* accum_out, void* stream_);
+int lrt_backward_accum(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
+                       const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
+                       const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
+                       float* d_opac, float* d_scales, float* d_rots, float* accum_out, void* stream_)
+{
+    if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null state");
+    DeviceGuard dg(st->device);
+    rec_begin(st, stream_);
+    return rec_end(st, backward_impl(st, H, W, ray_o, ray_d, P, M, deg, means, scales, rots, opac, shs, bg, out9, dL_dout9, d_means, d_shs, d_opac, d_scales, d_rots, accum_out, stream_),
+                   (hipStream_t)stream_);
+}
 int lrt_backward(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
                  const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
                  const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
                  float* d_opac, float* d_scales, float* d_rots, void* stream_)
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_backward: null state");
-    DeviceGuard dg(st->device);
-    rec_begin(st, stream_);
-    return rec_end(st, backward_impl(st, H, W, ray_o, ray_d, P, M, deg, means, scales, rots, opac, shs, bg, out9, dL_dout9, d_means, d_shs, d_opac, d_scales, d_rots, stream_),
-                   (hipStream_t)stream_);
+    // option deferred_accum: the accum tensor of the most recent training forward is completed by this backward -- if it IS that forward's
+    // (a caller that runs other forwards in between hands the tensor over itself: lrt_backward_accum)
+    float* const acc = (st->deferred_accum && st->acc_pending && st->acc_serial == st->fwd_serial) ? st->acc_ptr : nullptr;
+    return lrt_backward_accum(st, H, W, ray_o, ray_d, P, M, deg, means, scales, rots, opac, shs, bg, out9, dL_dout9, d_means, d_shs, d_opac, d_scales, d_rots, acc, stream_);
 }
 static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
                          const float* means, const float* scales, const float* rots, const float* opac, const float* shs,
                          const float* bg, const float* out9, const float* dL_dout9, float* d_means, float* d_shs,
-                         float* d_opac, float* d_scales, float* d_rots, void* stream_)
+                         float* d_opac, float* d_scales, float* d_rots, float* accum_out, void* stream_)
 {
     int rc = check_common("lrt_backward", st, H, W, P, M, deg);
     if (rc) return rc;
@@ -1796,12 +1637,13 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
     // flat tensor) are filled at once
     auto zero_grads = [&]() -> int {
         if (P <= 0 || st->grads_prezeroed) return LRT_OK;
-        struct Seg { float* p; size_t n; } seg[5] = {{d_means, (size_t)P * 3}, {d_shs, (size_t)P * M * 3}, {d_opac, (size_t)P},
-                                                      {d_scales, (size_t)P * 2}, {d_rots, (size_t)P * 4}};
-        for (int i = 1; i < 5; i++) for (int j = i; j > 0 && seg[j].p < seg[j - 1].p; j--) { Seg t = seg[j]; seg[j] = seg[j - 1]; seg[j - 1] = t; }
-        for (int i = 0; i < 5;) {
+        constexpr int NS = 6;
+        struct Seg { float* p; size_t n; } seg[NS] = {{d_means, (size_t)P * 3}, {d_shs, (size_t)P * M * 3}, {d_opac, (size_t)P},
+                                                       {d_scales, (size_t)P * 2}, {d_rots, (size_t)P * 4}, {accum_out, accum_out ? (size_t)P : 0}};
+        for (int i = 1; i < NS; i++) for (int j = i; j > 0 && seg[j].p < seg[j - 1].p; j--) { Seg t = seg[j]; seg[j] = seg[j - 1]; seg[j - 1] = t; }
+        for (int i = 0; i < NS;) {
             float* b = seg[i].p; size_t n = seg[i].n; int j = i + 1;
-            while (j < 5 && seg[j].p == b + n) { n += seg[j].n; j++; }
+            while (j < NS && seg[j].p == b + n) { n += seg[j].n; j++; }
             if (n) HIPCHK(lrt_memset_async(st->lrec, b, 0, n * sizeof(float), stream));
             i = j;
         }
@@ -1813,6 +1655,7 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
     tp.means = means; tp.scales = scales; tp.rots = rots; tp.opac = opac; tp.mod = st->mod;
     tp.out9_in = out9; tp.dL_dout = dL_dout9; tp.prezeroed = st->grads_prezeroed;
     tp.d_means = d_means; tp.d_shs = d_shs; tp.d_opac = d_opac; tp.d_scales = d_scales; tp.d_rots = d_rots;
+    tp.accum = accum_out;                                       // non-null (option deferred_accum): every path below also writes the per-Gaussian sums of composite weights
     // the re-tracing backward finds the rays with a quad closer than 0.2 m itself and replays them like k_fwd_near does (lrt_near.inc)
     if (st->near_list && (size_t)H * W <= st->near_cap) { tp.near_list = st->near_list + st->near_cap; tp.near_count = st->ctrl + 24; tp.near_done = st->ctrl + 25; tp.naos = (const float*)st->nodes_aos; }
     if (st->hits_valid && st->replay_enabled && st->hit_H == H && st->hit_W == W) {
@@ -1823,7 +1666,7 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
         // the re-tracing fallback (enqueued behind it, returns at once when not needed).  Only the first backward of an image size
         // waits for the forward.
         bool ready = hipEventQuery(st->hit_ev) == hipSuccess;
-        const bool can_spec = st->spec_bwd && st->bwd_mode >= 2 && st->est_valid && st->est_hw == (size_t)H * W && st->hit_keys;
+        const bool can_spec = st->spec_bwd && st->bwd_mode >= 2 && st->est_valid && st->est_hw == (size_t)H * W && st->key_cap > 0;
         if (!ready && !can_spec) { HIPCHK(hipEventSynchronize(st->hit_ev)); ready = true; }
         unsigned n_hits = 0; bool record_ok = true, spec = false;
         st->last_bwd_spec = ready ? 0 : 1;
@@ -1841,7 +1684,7 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
             tp.n_tiles = tp.tiles_x * tp.tiles_y; tp.nsh = (deg + 1) * (deg + 1);
             tp.hit_t = st->hit_t; tp.hit_g = st->hit_g; tp.hit_n = st->hit_n; tp.hit_cap = st->hit_cap_alloc < st->hit_cap ? st->hit_cap_alloc : st->hit_cap;
             tp.hw = H * W; tp.hit_ovf = st->hit_ovf;
-            const bool sorted = (st->bwd_mode >= 2) && st->hit_keys && n_hits <= st->key_cap;
+            const bool sorted = (st->bwd_mode >= 2) && st->key_cap > 0 && n_hits <= st->key_cap;      // the record buffers hold the frame's hits
             // bucketed reduction (bwd_mode 3): buckets of 2^shift consecutive Gaussian indices, about 4096 of them (S1M: 256 per bucket 0.370 ms,
             // 128: 0.390, 512: 0.379); the ray index and the index inside the bucket share one 32-bit word of the hit's record
             int bk_shift = 5; long long bk_nb = 0;
@@ -1852,7 +1695,8 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
             }
             // a gradient row goes out with one lane per component (bk_row_out): 10 + 3 M <= 64, i.e. M <= 18; wider SH tables (M = 25 with an
             // active degree <= 3) take the sorted path, which zero-fills the tensors first
-            const bool bucket = bk_nb > 0 && bk_nb <= BK_MAX_NB && ((unsigned long long)H * W) < (1ull << (32 - bk_shift)) && tp.n_tiles > 0 && (spec || n_hits > 0) && 10 + 3 * M <= 64;
+            const bool bucket = bk_nb > 0 && bk_nb <= BK_MAX_NB && ((unsigned long long)H * W) < (1ull << (32 - bk_shift)) && tp.n_tiles > 0 && (spec || n_hits > 0) && 10 + 3 * M + (accum_out ? 1 : 0) <= 64
+                                && (LRT_HAS_LEGACY || st->fast_valid);      // (the product's per-ray preparation reads the colour pass's record: k_bwd_prep2)
             if (!bucket) { rc = zero_grads(); if (rc) return rc; }
             if (bucket) {
                 ScopedTimer tm(st, 2, stream);
@@ -1881,12 +1725,16 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 if (lds_nb > 48 * 1024) {
                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                     if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+#ifdef LRT_LEGACY
                     else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
+#endif
                 }
                 lrt_launch(st->lrec, k_bk_count, dim3(ng), dim3(256), lds_nb, stream, tp);
                 lrt_launch(st->lrec, k_bk_scan, dim3((unsigned)((bk_nb + 63) / 64), BK_RB), dim3(1024), 0, stream, tp);
                 if (tp.fast_prep) lrt_launch(st->lrec, k_bwd_prep2, dim3(ng), dim3(1024), lds_nb, stream, tp);     // hit_pk keeps the forward's colours: a second backward may use them again
+#ifdef LRT_LEGACY
                 else lrt_launch(st->lrec, (k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
+#endif
                 lrt_launch(st->lrec, k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
                 lrt_launch(st->lrec, k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise; k_bk_sort left rows of zeros)
@@ -1897,6 +1745,7 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 HIPCHK(hipGetLastError());
                 return LRT_OK;
             }
+#ifdef LRT_LEGACY      // bwd_mode 1 (replay + atomics) and 2 (sorted reduction): the cross-check library only
             if (tp.n_tiles > 0 && !sorted) {
                 ScopedTimer tm(st, 2, stream);
                 lrt_launch(st->lrec, k_bwd_replay<true>, dim3((tp.n_tiles + 3) / 4), dim3(256), 0, stream, tp);
@@ -1943,6 +1792,12 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
             }
             HIPCHK(hipGetLastError());
             return LRT_OK;
+#else
+            // no bucketed replay for this call (SH table wider than a wave's row, a forward of the packet kernel, more than 16384 buckets): re-trace.
+            // The gradients were cleared above; a speculated record decision is moot (the re-trace is unconditional: guard 0)
+            tp.guard = 0; tp.n_hits_dev = nullptr;
+            return launch_trace(st, tp, true, stream);
+#endif
         }
         // a ray composited more hits than the record holds: this frame is re-traced (an order of magnitude slower); absorb_status
         // has doubled the capacity for the following ones

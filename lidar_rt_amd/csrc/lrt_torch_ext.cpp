@@ -198,7 +198,7 @@ trace_surfels_backward(State& st, const at::Tensor& ray_o, const at::Tensor& ray
                        const at::Tensor& rotations, const c10::optional<at::Tensor>& transMat_precomp, const c10::optional<at::Tensor>& viewmatrix,
                        const c10::optional<at::Tensor>& projmatrix, const c10::optional<at::Tensor>& campos, bool prefiltered, bool debug,
                        const at::Tensor& out_attr_float32, const c10::optional<at::Tensor>& out_attr_uint32, const at::Tensor& dL_dout_attr_float32,
-                       const py::object& grads_out, const py::object& forward_serial)
+                       const py::object& grads_out, const py::object& forward_serial, const c10::optional<at::Tensor>& accum_out)
 {
     (void)vertices; (void)viewmatrix; (void)projmatrix; (void)campos; (void)prefiltered; (void)debug; (void)out_attr_uint32; (void)scale_modifier;
     const int64_t P = prep(ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations, transMat_precomp);
@@ -235,11 +235,18 @@ trace_surfels_backward(State& st, const at::Tensor& ray_o, const at::Tensor& ray
         TORCH_CHECK(ok(d_means, {P, 3}) && ok(d_shs, {P, M, 3}) && ok(d_opac, {P, 1}) && ok(d_scales, {P, 2}) && ok(d_rot, {P, 4}),
                     "grads_out tensors must be contiguous float32 device tensors of the gradient shapes");
     }
+    // option deferred_accum: the (P,) accum tensor the forward returned all-zero is completed here (lrt_backward_accum)
+    at::Tensor acc;
+    if (accum_out.has_value() && accum_out->defined()) {
+        acc = *accum_out;
+        TORCH_CHECK(acc.dim() == 1 && acc.size(0) == P && acc.is_contiguous() && acc.scalar_type() == at::kFloat && acc.device() == means3D.device(),
+                    "accum_out must be a contiguous float32 device tensor of shape (P,)");
+    }
     {
         c10::hip::HIPGuard guard(idx);
-        check_rc(lrt_backward(h, (int)H, (int)W, fptr(ro), fptr(rd), (int)P, (int)M, degree, fptr(m), fptr(s), fptr(r), fptr(o), fptr(sh), fptr(bg),
-                              fptr(out), fptr(dL), fptr_mut(d_means), fptr_mut(d_shs), fptr_mut(d_opac), fptr_mut(d_scales), fptr_mut(d_rot),
-                              (void*)c10::hip::getCurrentHIPStream(idx).stream()), "lrt_backward");
+        check_rc(lrt_backward_accum(h, (int)H, (int)W, fptr(ro), fptr(rd), (int)P, (int)M, degree, fptr(m), fptr(s), fptr(r), fptr(o), fptr(sh), fptr(bg),
+                                    fptr(out), fptr(dL), fptr_mut(d_means), fptr_mut(d_shs), fptr_mut(d_opac), fptr_mut(d_scales), fptr_mut(d_rot),
+                                    acc.defined() ? fptr_mut(acc) : nullptr, (void*)c10::hip::getCurrentHIPStream(idx).stream()), "lrt_backward");
     }
     if (!own) return py::make_tuple(d_means, d_shs, py::none(), d_opac, d_scales, d_rot, py::none(), py::none());
     // dead outputs of the reference (never written by backward.cu; trace_surfels.cpp:322-329 zero-fills them): zeros of the same shapes
@@ -284,5 +291,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod)
             py::arg("means3D"), py::arg("shs"), py::arg("degree"), py::arg("colors_precomp"), py::arg("opacities"), py::arg("scales"), py::arg("scale_modifier"),
             py::arg("rotations"), py::arg("transMat_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("campos"), py::arg("prefiltered"),
             py::arg("debug"), py::arg("out_attr_float32"), py::arg("out_attr_uint32"), py::arg("dL_dout_attr_float32"), py::arg("grads_out") = py::none(),
-            py::arg("forward_serial") = py::none());
+            py::arg("forward_serial") = py::none(), py::arg("accum_out") = py::none());
 }

@@ -318,7 +318,8 @@ def _ct_trace_surfels(state, training: bool, ray_o, ray_d, vertices, background,
 def _ct_trace_surfels_backward(state, ray_o, ray_d, vertices, background, means3D, shs,
                            degree: int, colors_precomp, opacities, scales, scale_modifier: float, rotations,
                            transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
-                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None):
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None, accum_out=None):
+    # accum_out (extension, option deferred_accum): the (P,) accum tensor the forward returned all-zero; this backward writes the sums
     # grads_out (extension): dict of preallocated contiguous fp32 tensors 'means' (P,3), 'shs' (P,M,3), 'opacities' (P,1),
     # 'scales' (P,2), 'rotations' (P,4) to write into (e.g. views of one flat buffer for a fused all-reduce)
     P = _prep(state, ray_o, ray_d, background, means3D, shs, colors_precomp, opacities, scales, rotations,
@@ -354,12 +355,14 @@ def _ct_trace_surfels_backward(state, ray_o, ray_d, vertices, background, means3
         for t_, shp in ((d_means, (P, 3)), (d_shs, (P, M, 3)), (d_opac, (P, 1)), (d_scales, (P, 2)), (d_rot, (P, 4))):
             if tuple(t_.shape) != shp or not t_.is_contiguous() or t_.dtype != torch.float32 or t_.device != dev:
                 raise RuntimeError("grads_out tensors must be contiguous float32 device tensors of the gradient shapes")
+    if accum_out is not None and (tuple(accum_out.shape) != (P,) or not accum_out.is_contiguous() or accum_out.dtype != torch.float32 or accum_out.device != dev):
+        raise RuntimeError("accum_out must be a contiguous float32 device tensor of shape (P,)")
     with torch.cuda.device(idx):
-        _capi.check(state._lib.lrt_backward(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
-                                            _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o), _capi.ptr(sh),
-                                            _capi.ptr(bg), _capi.ptr(out), _capi.ptr(dL), _capi.ptr(d_means),
-                                            _capi.ptr(d_shs), _capi.ptr(d_opac), _capi.ptr(d_scales),
-                                            _capi.ptr(d_rot), _stream_ptr()), "lrt_backward")
+        _capi.check(state._lib.lrt_backward_accum(h, H, W, _capi.ptr(ro), _capi.ptr(rd), P, M, int(degree),
+                                                  _capi.ptr(m), _capi.ptr(s), _capi.ptr(r), _capi.ptr(o), _capi.ptr(sh),
+                                                  _capi.ptr(bg), _capi.ptr(out), _capi.ptr(dL), _capi.ptr(d_means),
+                                                  _capi.ptr(d_shs), _capi.ptr(d_opac), _capi.ptr(d_scales),
+                                                  _capi.ptr(d_rot), _capi.ptr(accum_out), _stream_ptr()), "lrt_backward")
     if grads_out is not None:
         return d_means, d_shs, None, d_opac, d_scales, d_rot, None, None
     # dead outputs of the reference (never written by backward.cu): returned as zeros
@@ -392,8 +395,8 @@ def trace_surfels(state, training: bool, ray_o, ray_d, vertices, background, mea
 
 def trace_surfels_backward(state, ray_o, ray_d, vertices, background, means3D, shs, degree: int, colors_precomp, opacities, scales,
                            scale_modifier: float, rotations, transMat_precomp, viewmatrix, projmatrix, campos, prefiltered: bool, debug: bool,
-                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None):
+                           out_attr_float32, out_attr_uint32, dL_dout_attr_float32, grads_out=None, forward_serial=None, accum_out=None):
     return (_ext.trace_surfels_backward if _is_ext(state) else _ct_trace_surfels_backward)(
         state, ray_o, ray_d, vertices, background, means3D, shs, degree, colors_precomp, opacities, scales, scale_modifier, rotations,
         transMat_precomp, viewmatrix, projmatrix, campos, prefiltered, debug, out_attr_float32, out_attr_uint32, dL_dout_attr_float32,
-        grads_out=grads_out, forward_serial=forward_serial)
+        grads_out=grads_out, forward_serial=forward_serial, accum_out=accum_out)

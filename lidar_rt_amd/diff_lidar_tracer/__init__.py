@@ -49,6 +49,8 @@ class _Tracer(torch.autograd.Function):
             state.check(means3D.device, wait=True)
         ctx.tracer_settings = ts
         ctx.state = state
+        # option deferred_accum: a training forward returned `accum` all-zero; the backward of THIS forward writes the sums into the same tensor
+        ctx.accum_out = accum if (training and getattr(state, "deferred_accum", False)) else None
         ctx.forward_serial = getattr(state, "last_serial", None)
         ctx.save_for_backward(ray_o, ray_d, vertices, means3D, shs, colors_precomp, opacities, scales, rotations,
                               cov3Ds_precomp, out_f32, out_i32)
@@ -63,7 +65,7 @@ class _Tracer(torch.autograd.Function):
         (g_means, g_shs, g_colors, g_opac, g_scales, g_rot, g_cov, g_g3) = _C.trace_surfels_backward(
             ctx.state, ray_o, ray_d, vertices, ts.bg, means3D, shs, ts.sh_degree, colors_precomp, opacities, scales,
             ts.scale_modifier, rotations, cov3Ds_precomp, ts.viewmatrix, ts.projmatrix, ts.campos, ts.prefiltered,
-            ts.debug, out_f32, out_i32, grad_out_f32, forward_serial=ctx.forward_serial)
+            ts.debug, out_f32, out_i32, grad_out_f32, forward_serial=ctx.forward_serial, accum_out=ctx.accum_out)
         g_opac = g_opac.reshape(opacities.shape)
         g_colors = g_colors if colors_precomp.numel() > 0 else None
         g_cov = g_cov if cov3Ds_precomp.numel() > 0 else None
@@ -71,13 +73,21 @@ class _Tracer(torch.autograd.Function):
 
 
 class Tracer(nn.Module):
-    def __init__(self) -> None:
+    def __init__(self, deferred_accum: bool = False) -> None:
+        """deferred_accum (addition; the reference's constructor takes no argument): in training mode with a backward to follow, the
+        forward returns `accum` ALL-ZERO and ``loss.backward()`` fills the SAME tensor (the per-Gaussian sums of composite weights,
+        forward.cu:268) -- the reference's loop reads them only after the backward (train.py:156,219), and the forward saves one float
+        atomic per composited hit.  Evaluation-mode forwards and forwards without a backward stay exact at once."""
         super().__init__()
         # the reference creates its OptiX context here (zero-argument ctor, module-level singleton in
         # lib/gaussian_renderer/__init__.py:11); ours is a cheap host object, device state is created lazily
         self.optix_context = _C.OptiXStateWrapper("")
         self.vertices = None
         self.deferred_checks = False     # True: forwards without a backward do not wait for the trace; call check() once per batch
+        self.deferred_accum = bool(deferred_accum)
+        if self.deferred_accum:
+            self.optix_context.deferred_accum = True
+            self.optix_context.set_option("deferred_accum", 1)
 
     # ---- reference surface -------------------------------------------------------------------
     def build_acceleration_structure(self, vertices: torch.Tensor, triangles: torch.Tensor, rebuild: bool = 1):

@@ -94,11 +94,12 @@ class HipBackend:
         self.last_serial = self.state.last_serial      # identifies the hit record this forward left in the library state
         return out, accum
 
-    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0, grads_out=None, forward_serial=None):
+    def backward(self, ray_o, ray_d, means, scales, rotations, opacities, shs, deg, bg, out, dL, mod=1.0, grads_out=None, forward_serial=None,
+                 accum_out=None):
         e = torch.empty(0, device=means.device)
         g = self._C.trace_surfels_backward(self.state, ray_o, ray_d, e, bg, means, shs, deg, e, opacities, scales,
                                            mod, rotations, e, e, e, e, False, False, out, None, dL, grads_out=grads_out,
-                                           forward_serial=forward_serial)
+                                           forward_serial=forward_serial, accum_out=accum_out)
         return {"means": g[0], "shs": g[1], "opacities": g[3], "scales": g[4], "rotations": g[5]}
 
     def defer_errors(self, on: bool = True):
@@ -130,8 +131,12 @@ _TAKES_CACHE: Dict[tuple, bool] = {}
 class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
-    def __init__(self, backend=None, group=None, exchange: str = "sparse", world: Optional[int] = None, rank: Optional[int] = None):
-        """exchange: "owner" = rows of touched Gaussians go to their owning rank (complete gradient on the owner only); "dense" = one
+    def __init__(self, backend=None, group=None, exchange: str = "sparse", world: Optional[int] = None, rank: Optional[int] = None,
+                 deferred_accum: bool = False):
+        """deferred_accum: the local forward leaves the hit weights `accum` all-zero and the local BACKWARD writes them (library option
+        deferred_accum, lrt_backward_accum) -- straight into the flat exchange buffer when there is an exchange.  A training step reads the
+        weights after the backward only (train.py:156,219); callers that need them from the forward keep the default.
+        exchange: "owner" = rows of touched Gaussians go to their owning rank (complete gradient on the owner only); "dense" = one
         all_reduce of the flat gradient buffer (replicated); "sparse" = all_gather of the touched rows (replicated); "auto" = sparse
         unless the ranks together touched more than `sparse_max_fraction` of the Gaussians, then dense.
         world / rank: override what `torch.distributed` reports -- world=1 makes a plain single-rank tracer inside a multi-rank job
@@ -143,6 +148,9 @@ class ShardedTracer:
         self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | "owner" | None
         self.last_owner: Optional[torch.Tensor] = None  # (P,) int32 owner map of the last "owner" exchange
         self.backend = backend if backend is not None else HipBackend()
+        self.deferred_accum = bool(deferred_accum) and isinstance(self.backend, HipBackend)
+        if self.deferred_accum:
+            self.backend.state.set_option("deferred_accum", 1)
         self.group = group
         self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = int(rank) if rank is not None else (dist.get_rank(group) if (dist.is_initialized() and world is None) else 0)
@@ -517,6 +525,10 @@ class ShardedTracer:
             self._flat_dirty = True                                        # until this step has left its lists behind
         if self._backend_takes(self.backend.backward, "grads_out"):
             kw = {"forward_serial": fc.get("serial")} if self._backend_takes(self.backend.backward, "forward_serial") else {}
+            if self.deferred_accum:
+                # the backward completes the weights: into the forward's own (all-zero) tensor, or -- with an exchange to follow -- straight into
+                # the flat buffer's accum view (no 4 P-byte copy; under the prezero protocol that view is all-zero on entry like the rest)
+                kw["accum_out"] = lay.views["accum"] if exchanging else accum_loc_
             self.backend.backward(ro_, rd_, means, scales, rotations, opacities, shs, deg, bg,
                                   out_loc_, dL, mod, grads_out=direct, **kw)     # kernels write straight into the flat buffer
         else:                                                                     # backend without grads_out (test stand-ins)
@@ -535,7 +547,8 @@ class ShardedTracer:
                 self._xchg_pack(lay, msg, cap, accum_loc_, with_rows=False)
                 self._prev_lists, self._flat_dirty = (msg, 1, cap, words), False
             return {**lay.views, "accum": accum_loc_}          # nothing to exchange: the forward's own accum tensor, no 4 P-byte copy
-        lay.views["accum"].copy_(accum_loc_)
+        if not self.deferred_accum:
+            lay.views["accum"].copy_(accum_loc_)
         if reduce and (self.world > 1 or self.force_collectives):
             with self._Region(self, "gradient_exchange", lay.flat.device):
                 mode = self.exchange
@@ -547,24 +560,6 @@ class ShardedTracer:
                     dist.all_reduce(lay.flat, op=dist.ReduceOp.SUM, group=self.group)
                     self.last_exchange = "dense"
         return lay.views
-
-    @staticmethod
-    def _grad_rows(fn: str, lay: GradLayout, n: int, ids: torch.Tensor, rows: torch.Tensor):
-        """lrt_grad_gather / lrt_grad_scatter_add (include/lrt.h) on the views of the flat buffer."""
-        import ctypes as C
-        from . import _capi
-        v, p = lay.views, _capi.ptr
-        dev = rows.device
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        dense = (p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]))
-        lib = _capi.load()
-        with torch.cuda.device(idx):
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if fn == "lrt_grad_gather":
-                rc = lib.lrt_grad_gather(idx, lay.P, lay.M, int(n), p(ids), *dense, p(rows), stream)
-            else:
-                rc = lib.lrt_grad_scatter_add(idx, lay.P, lay.M, int(n), p(ids), p(rows), *dense, stream)
-        _capi.check(rc, fn)
 
     def _all_gather_rows(self, t: torch.Tensor):
         """all_gather of equally shaped tensors; one flat receive buffer when the backend offers it (RCCL), so that the
@@ -597,17 +592,6 @@ class ShardedTracer:
         """owner[g] (int32): the rank whose slab axis is closest to the direction sensor -> Gaussian g (ties: the lowest rank)."""
         origin, axes = self.slab_axes()
         P = means.shape[0]
-        if means.is_cuda:
-            import ctypes as C
-            from . import _capi
-            owner = torch.empty(P, dtype=torch.int32, device=means.device)
-            idx = means.device.index if means.device.index is not None else torch.cuda.current_device()
-            m = means.detach().contiguous()
-            with torch.cuda.device(idx):
-                _capi.check(_capi.load().lrt_owner_by_direction(idx, P, _capi.ptr(m), _capi.ptr(origin), self.world, _capi.ptr(axes),
-                                                                _capi.ptr(owner), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                            "lrt_owner_by_direction")
-            return owner
         return ((means.detach() - origin) @ axes.T).argmax(1).to(torch.int32)     # torch's argmax also returns the first maximum
 
     # ---- helpers of the exchanges ------------------------------------------------------------------------------------------------
@@ -659,41 +643,26 @@ class ShardedTracer:
         self.last_owner = owner
         cap = self._start_cap(("owner", P, M, N), P, P // (4 * N) + 1024)
         v = lay.views
-        hip = dev.type == "cuda"
-        if hip:
-            import ctypes as C
-            from . import _capi
-            p = _capi.ptr
-            di = dev.index if dev.index is not None else torch.cuda.current_device()
+        # (round 6: the device helpers of this non-default exchange left the library; torch's index ops move the rows)
         while True:
             blk = 1 + cap + cap * width                                   # int32 words per (source, owner) block: count | indices | rows
             send = self._buf("own_send", (N, blk), torch.int32, dev); recv = self._buf("own_recv", (N, blk), torch.int32, dev)
             cnt = send[:, 0]                                              # written in place: the message needs no assembly
             idx = send[:, 1:1 + cap]
             rows = send[:, 1 + cap:].view(torch.float32).view(N, cap, width)
-            if hip:
-                # the pack kernels address (N, cap) / (N, cap, width) arrays with their own strides: pack into contiguous scratch, copy in
-                cnt_c = self._buf("own_cnt", (N,), torch.int32, dev); idx_c = self._buf("own_idx", (N, cap), torch.int32, dev)
-                rows_c = self._buf("own_rows", (N, cap, width), torch.float32, dev)
-                with torch.cuda.device(di):
-                    _capi.check(_capi.load().lrt_grad_pack_foreign(di, P, M, N, rank, cap, p(owner), p(v["means"]), p(v["scales"]), p(v["rotations"]),
-                                                                   p(v["opacities"]), p(v["shs"]), p(v["accum"]), p(idx_c), p(cnt_c), p(rows_c),
-                                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lrt_grad_pack_foreign")
-                cnt.copy_(cnt_c); idx.copy_(idx_c); rows.copy_(rows_c)
-            else:
-                touched = (v["accum"] > 0)
-                cnt.zero_()
-                for d in range(N):
-                    if d == rank:
-                        continue
-                    g = torch.nonzero(touched & (owner == d)).squeeze(1)
-                    cnt[d] = g.numel()
-                    g = g[:cap]
-                    idx[d, :g.numel()] = g.to(torch.int32)
-                    col = 0
-                    for name, k in self._row_fields(M):
-                        rows[d, :g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
-                        col += k
+            touched = (v["accum"] > 0)
+            cnt.zero_()
+            for d in range(N):
+                if d == rank:
+                    continue
+                g = torch.nonzero(touched & (owner == d)).squeeze(1)
+                cnt[d] = g.numel()
+                g = g[:cap]
+                idx[d, :g.numel()] = g.to(torch.int32)
+                col = 0
+                for name, k in self._row_fields(M):
+                    rows[d, :g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
+                    col += k
             dist.all_to_all_single(recv, send, group=self.group)
             rcnt = recv[:, 0].contiguous()
             # in-step verification: no pair may have overflowed anywhere -- every rank learns the global maximum
@@ -709,20 +678,12 @@ class ShardedTracer:
         for s_ in range(N):                                               # fixed order of the sources -> a deterministic sum
             if s_ == rank:
                 continue
-            if hip:
-                ri = ridx[s_].contiguous(); rr = rrows[s_].contiguous()
-                with torch.cuda.device(di):
-                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(rcnt[s_:s_ + 1]), p(ri), p(rr), p(v["means"]),
-                                                                          p(v["scales"]), p(v["rotations"]), p(v["opacities"]), p(v["shs"]),
-                                                                          p(v["accum"]), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                                "lrt_grad_scatter_add_counted")
-            else:
-                c = min(int(rcnt[s_]), cap)
-                g = ridx[s_, :c].long()
-                col = 0
-                for name, k in self._row_fields(M):
-                    v[name].view(P, k).index_add_(0, g, rrows[s_, :c, col:col + k])
-                    col += k
+            c = min(int(rcnt[s_]), cap)
+            g = ridx[s_, :c].long()
+            col = 0
+            for name, k in self._row_fields(M):
+                v[name].view(P, k).index_add_(0, g, rrows[s_, :c, col:col + k])
+                col += k
         self._adapt_cap(biggest)
         self.last_exchange = "owner"
 
@@ -831,31 +792,20 @@ class ShardedTracer:
         width = lay.width
         dev = lay.flat.device
         v = lay.views
-        hip = dev.type == "cuda"
+        # (round 6: the device helpers of this round-3 exchange left the library; the training exchange is _exchange_lists)
         cap = self._start_cap(("sparse", P, M, N), P, P // (2 * N) + 1024)
-        if hip:
-            import ctypes as C
-            from . import _capi
-            p = _capi.ptr
-            di = dev.index if dev.index is not None else torch.cuda.current_device()
-            stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
         while True:
             blk = 1 + cap + cap * width
             msg = self._buf("sp_send", (blk,), torch.int32, dev)
             cnt, idx, rows = msg[0:1], msg[1:1 + cap], msg[1 + cap:].view(torch.float32).view(cap, width)
-            if hip:
-                with torch.cuda.device(di):
-                    _capi.check(_capi.load().lrt_grad_pack_touched(di, P, M, cap, p(v["means"]), p(v["scales"]), p(v["rotations"]), p(v["opacities"]),
-                                                                   p(v["shs"]), p(v["accum"]), p(idx), p(cnt), p(rows), stream()), "lrt_grad_pack_touched")
-            else:
-                g = torch.nonzero(v["accum"] > 0).squeeze(1)
-                cnt[0] = g.numel()
-                g = g[:cap]
-                idx[:g.numel()] = g.to(torch.int32)
-                col = 0
-                for name, k in self._row_fields(M):
-                    rows[:g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
-                    col += k
+            g = torch.nonzero(v["accum"] > 0).squeeze(1)
+            cnt[0] = g.numel()
+            g = g[:cap]
+            idx[:g.numel()] = g.to(torch.int32)
+            col = 0
+            for name, k in self._row_fields(M):
+                rows[:g.numel(), col:col + k] = v[name].reshape(P, k).index_select(0, g)
+                col += k
             parts = self._all_gather_rows(msg)
             counts = [int(c) for c in self._to_host(torch.stack([q[0] for q in parts]))]
             biggest = max(counts)
@@ -867,31 +817,20 @@ class ShardedTracer:
             self._adapt_cap(biggest)
             return False                                                  # nothing was modified: the caller all-reduces the flat buffer
         # clear what this rank wrote (its own touched rows), then add every rank's list in rank order
-        if hip:
-            with torch.cuda.device(di):
-                _capi.check(_capi.load().lrt_grad_zero_rows_counted(di, P, M, cap, p(cnt), p(idx), p(v["means"]), p(v["scales"]), p(v["rotations"]),
-                                                                    p(v["opacities"]), p(v["shs"]), p(v["accum"]), stream()), "lrt_grad_zero_rows_counted")
-        else:
-            g = idx[:counts[rank]].long()
-            for name, k in self._row_fields(M):
-                v[name].view(P, k).index_fill_(0, g, 0.0)
+        g = idx[:counts[rank]].long()
+        for name, k in self._row_fields(M):
+            v[name].view(P, k).index_fill_(0, g, 0.0)
         for r in range(N):
             c = counts[r]
             if c == 0:
                 continue
             q = parts[r]
             ridx, rrows = q[1:1 + cap], q[1 + cap:].view(torch.float32).view(cap, width)
-            if hip:
-                with torch.cuda.device(di):
-                    _capi.check(_capi.load().lrt_grad_scatter_add_counted(di, P, M, cap, p(q[0:1]), p(ridx), p(rrows), p(v["means"]), p(v["scales"]),
-                                                                          p(v["rotations"]), p(v["opacities"]), p(v["shs"]), p(v["accum"]), stream()),
-                                "lrt_grad_scatter_add_counted")
-            else:
-                g = ridx[:c].long()
-                col = 0
-                for name, k in self._row_fields(M):
-                    v[name].view(P, k).index_add_(0, g, rrows[:c, col:col + k])
-                    col += k
+            g = ridx[:c].long()
+            col = 0
+            for name, k in self._row_fields(M):
+                v[name].view(P, k).index_add_(0, g, rrows[:c, col:col + k])
+                col += k
         self._adapt_cap(biggest)
         self.last_exchange = "sparse"
         return True

@@ -29,6 +29,12 @@ def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
                         aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
 
 
+# Deferred hit weights (addition; default off = the reference's contract: `accum_gaussian_weight` is complete when raytracing() returns).
+# True: a render that a backward will follow (the tracer is in training mode, grad mode on) returns the weights ALL-ZERO and
+# loss.backward() fills the same tensor -- train.py reads them after the backward only (:156, :219) -- which takes one float atomic per
+# composited hit out of the forward (Tracer(deferred_accum=True), lrt_backward_accum).  Evaluation renders are exact at once either way.
+deferred_accum = False
+
 use_fused_preprocess = True   # module switch: False forces the getter chain of the reference (used by the tests)
 
 # Multi-GPU: set to a lidar_rt_amd.parallel.ShardedTracer and raytracing() traces this rank's azimuth slab only, all-gathers the
@@ -93,8 +99,8 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
                decomp=False):
     global tracer_2dgs
     if sharded is None:
-        if tracer_2dgs is None:
-            tracer_2dgs = Tracer()
+        if tracer_2dgs is None or tracer_2dgs.deferred_accum != bool(deferred_accum):
+            tracer_2dgs = Tracer(deferred_accum=bool(deferred_accum))
         # opt.bvh_refit_interval = K > 0: K refits (lrt_refit: same order and topology, new records and boxes) between full LBVH
         # builds while the number of Gaussians is unchanged; results do not depend on it.  0 = rebuild every call (the reference)
         tracer_2dgs.optix_context.refit_interval = int(getattr(getattr(args, "opt", None), "bvh_refit_interval", 0) or 0)

@@ -8,6 +8,18 @@ DEV = torch.device("cuda:0")
 DEFAULT_OPTS = {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "hit_cap": 256, "wg4_per_cu": 5, "c4_queue_limit": 1024, "c4_waves": 0, "slab0_mm": 100000, "root_nodes": 32, "learn_slab": 1, "spec_bwd": 1, "spec_margin": 65536, "own_sort": 2, "fused_tree": 1, "fused_hist": 1}     # the library defaults
 
 
+def legacy_library() -> bool:
+    """True when this process runs on the cross-check library (liblrt_hip_legacy.so, -DLRT_LEGACY: env LRT_HIP_LIB, set by
+    tests/test_legacy_crosscheck_gpu.py for its subprocess): the retired kernel generations (bwd_mode 1 / 2, defer_colour 0, fused_tree 0 / 2)
+    exist there and serve as independent implementations."""
+    from lidar_rt_amd import _capi
+    return _capi.has_legacy()
+
+
+def is_legacy_mode(opts) -> bool:
+    return opts.get("bwd_mode") in (1, 2) or opts.get("defer_colour") == 0 or opts.get("fused_tree", 1) != 1
+
+
 def settings(bg, deg, mod=1.0):
     e = torch.empty(0, device=DEV)
     return TracingSettings(None, None, None, None, torch.as_tensor(np.asarray(bg, np.float32), device=DEV), mod, e, e,

@@ -11,6 +11,8 @@ from oracle import chamfer as och
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
+from lidar_rt_amd import _capi
+CH_MODES = [0, 1] + ([3] if _capi.has_legacy() else [])      # 3 = the lane-per-query kernel kc_query: cross-check library only
 
 
 def lidar_clouds(H, W, seed, drop=0.15):
@@ -51,7 +53,7 @@ def rand_clouds(B, N, M, seed, scale=20.0):
     return a, b
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("mode", CH_MODES)
 @pytest.mark.parametrize("B,N,M", [(1, 1, 1), (1, 1, 700), (1, 700, 1), (1, 7, 9), (1, 64, 65), (2, 513, 4097),
                                    (3, 1000, 777), (1, 20000, 15000)])
 def test_forward_bit_exact_random(B, N, M, mode):
@@ -59,13 +61,13 @@ def test_forward_bit_exact_random(B, N, M, mode):
     assert_bit_exact(run_hip(a, b, mode), och.chamfer_forward(a, b))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("mode", CH_MODES)
 def test_forward_bit_exact_lidar_frame(mode):
     a, b = lidar_clouds(32, 1024, 5)
     assert_bit_exact(run_hip(a, b, mode), och.chamfer_forward(a, b))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("mode", CH_MODES)
 def test_exact_ties_keep_the_first_index(mode):
     r = np.random.default_rng(3)
     b = r.integers(-6, 7, (1, 5000, 3)).astype(np.float32)         # lattice: thousands of exact duplicates and ties

@@ -20,18 +20,34 @@ from lidar_rt_amd.diff_lidar_tracer import Tracer
 
 pytestmark = pytest.mark.gpu
 
+from lidar_rt_amd import _capi
 if torch.cuda.is_available():
     from tests.hip_util import run_hip, rel_l2, frac_outside, parity_report
     from tests.hip_util import DEFAULT_OPTS as DEFAULT_OPTS_
 
-MODES = [{"fwd_mode": 0, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "bwd_mode": 1, "defer_colour": 0},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 4}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 0, "defer_colour": 1},
-         {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 1}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 0},
-         {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 3},
-         {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "c4_waves": 16}]
+LEGACY = _capi.has_legacy()       # this process runs on liblrt_hip_legacy.so (tests/test_legacy_crosscheck_gpu.py starts it that way)
+needs_legacy = pytest.mark.skipif(not LEGACY, reason="cross-check of a retired kernel generation: runs on the -DLRT_LEGACY library (tests/test_legacy_crosscheck_gpu.py)")
+# the product library's modes: the collect & resolve forward with the bucketed replay (4 / 8 / 16 waves per tile, both build sorts), the
+# re-tracing backward, the packet kernel both ways.  All SH degrees for the first three, degree 3 for the rest.
+PRODUCT_MODES = [{"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1}, {"fwd_mode": 2, "bwd_mode": 0, "defer_colour": 1}, {"fwd_mode": 0, "bwd_mode": 0},
+                 {"fwd_mode": 0, "bwd_mode": 3}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "c4_waves": 4},
+                 {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "c4_waves": 16},
+                 {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "own_sort": 1}, {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 1, "own_sort": 0}]
+# ... and what only the cross-check library has: bwd_mode 1 / 2, colours inside the trace kernel
+LEGACY_MODES = [{"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "bwd_mode": 1, "defer_colour": 0},
+                {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1},
+                {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 0, "c4_waves": 8}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "c4_waves": 8},
+                {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 1}, {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "own_sort": 0},
+                {"fwd_mode": 2, "bwd_mode": 3, "defer_colour": 0}]
+DEGS = [(3, (0, 0, 1)), (0, (0, 0, 0)), (1, (0.3, 0.7, 0.2)), (2, (0, 0, 1))]
+MODE_CASES = [(m, dg, bg) for m in PRODUCT_MODES[:3] for dg, bg in DEGS] + [(m, 3, (0, 0, 1)) for m in PRODUCT_MODES[3:]]
+if LEGACY:      # the cross-check run: the retired modes (two SH degrees each), and the product's default beside them
+    MODE_CASES = [(m, dg, bg) for m in LEGACY_MODES for dg, bg in (DEGS[0], DEGS[2])] + [(PRODUCT_MODES[0], 3, (0, 0, 1))]
 GRADS = ("means", "scales", "rotations", "opacities", "shs")
+
+
+def _mode_id(m):
+    return f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else "") + (f"-sort{m['own_sort']}" if "own_sort" in m else "")
 
 
 def oracle_run(sc, o, d, deg, bg, dL=None, prec="f32", mod=1.0):
@@ -50,8 +66,7 @@ def s10k():
     return sc, o, d, dL
 
 
-@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"fwd{m['fwd_mode']}-bwd{m['bwd_mode']}" + ("-defer" if m.get("defer_colour") else "") + (f"-w{m['c4_waves']}" if m.get("c4_waves") else "") + (f"-sort{m['own_sort']}" if "own_sort" in m else ""))
-@pytest.mark.parametrize("deg,bg", [(3, (0, 0, 1)), (0, (0, 0, 0)), (1, (0.3, 0.7, 0.2)), (2, (0, 0, 1))])
+@pytest.mark.parametrize("mode,deg,bg", MODE_CASES, ids=[f"{_mode_id(m)}-deg{dg}" for m, dg, _ in MODE_CASES])
 def test_s10k_forward_backward_match_oracle(s10k, mode, deg, bg):
     sc, o, d, dL = s10k
     fw, bw = oracle_run(sc, o, d, deg, np.array(bg, np.float32), dL)
@@ -241,7 +256,7 @@ def _facing(xs, ops, sh_dc=(0.3, 0.1, -0.2)):
     return sc
 
 
-@pytest.mark.parametrize("mode", [MODES[3], MODES[0], MODES[4]], ids=["collect4", "legacy", "collect4-defer"])
+@pytest.mark.parametrize("mode", [PRODUCT_MODES[0], PRODUCT_MODES[2]] + ([LEGACY_MODES[2]] if LEGACY else []), ids=["collect4-defer", "packet"] + (["collect4"] if LEGACY else []))
 def test_known_answers(mode):
     o = np.zeros((1, 1, 3), np.float32); d = np.array([[[1.0, 0, 0]]], np.float32)
     # miss -> background
@@ -287,16 +302,22 @@ def test_empty_scene_and_unhittable_gaussians():
 
 def test_forward_modes_agree_and_backward_is_deterministic(s10k):
     sc, o, d, dL = s10k
-    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2})
-    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 0, "bwd_mode": 2})
+    bm = 2 if LEGACY else 3
+    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": bm})
+    b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 0, "bwd_mode": bm})
     assert rel_l2(a["out"], b["out"]) < 2e-5
-    c = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2})
+    c = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": bm})
     np.testing.assert_array_equal(a["out"], c["out"])                          # forward: hits ordered by (t, gidx), no atomics in the image
-    for k in GRADS:      # sorted reduction: run-to-run identical except where a Gaussian's hits span > 2 reduction chunks
-        assert rel_l2(a["grads"][k], c["grads"][k]) < 1e-7
-        assert (a["grads"][k] != c["grads"][k]).mean() < 1e-3
-    e = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "defer_colour": 0})     # colour in the trace kernel: other summation order
-    assert rel_l2(e["out"], a["out"]) < 1e-6
+    for k in GRADS:
+        # bucketed reduction: the order of the additions inside a Gaussian's run is the arrival order of integer LDS atomics (as with the
+        # reference's float atomics): run-to-run equal to rounding.  Sorted reduction (cross-check library): identical except where a
+        # Gaussian's hits span > 2 reduction chunks
+        assert rel_l2(a["grads"][k], c["grads"][k]) < (1e-7 if LEGACY else 1e-6)
+        if LEGACY:
+            assert (a["grads"][k] != c["grads"][k]).mean() < 1e-3
+    if LEGACY:
+        e = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "defer_colour": 0})     # colour in the trace kernel: other summation order
+        assert rel_l2(e["out"], a["out"]) < 1e-6
 
 
 def test_own_radix_sort_and_rocprim_give_the_same_results():
@@ -325,6 +346,7 @@ def _read_build(tr, which, n_bytes):
     return buf[:min(got, n_bytes) // 4]
 
 
+@needs_legacy
 @pytest.mark.parametrize("P", [5, 64, 65, 513, 4097, 40_000, 300_000])
 def test_fused_tree_build_equals_the_level_by_level_one(P):
     """k_make_tree (records + levels 1-3 per workgroup, boxes in LDS) + k_tree_top, and k_morton's fused digit histograms, against the
@@ -370,7 +392,7 @@ def test_bucketed_backward_against_the_sorted_one_on_awkward_index_layouts():
     for sc, (H, W) in cases:
         o, d = scenes.kitti_rays(H, W)
         dL = scenes.upstream_grad(H, W)
-        ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"bwd_mode": 2})
+        ref = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"bwd_mode": 2 if LEGACY else 0})      # product library: against the re-tracing backward's atomics
         for rep in range(2):                                                   # twice: the buffers of the first call are reused
             got = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"bwd_mode": 3})
             np.testing.assert_array_equal(got["out"], ref["out"])
@@ -430,7 +452,7 @@ def test_deferred_colour_beyond_the_hit_record(s10k):
     """More composited hits than the per-ray record holds: the deferred colour pass takes the rest from the overflow
     list (forward stays exact) and the backward falls back to re-tracing like the reference."""
     sc, o, d, dL = s10k
-    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "defer_colour": 0})
+    a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "defer_colour": 0} if LEGACY else {"fwd_mode": 2})      # (product: the record that holds every hit)
     for fm in (2,):
         b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": fm, "defer_colour": 1, "hit_cap": 4})
         assert rel_l2(b["out"], a["out"]) < 1e-5 and frac_outside(b["out"], a["out"], 1e-4) <= 1e-3
@@ -562,7 +584,8 @@ def test_dense_translucent_scene_overflows_every_capacity_once():
             assert rel_l2(f[k].reshape(ref.shape), ref) < 2e-2 and frac_outside(f[k].reshape(ref.shape), ref, 1e-3) <= 3e-2, k
         for f in frames[1:]:
             assert rel_l2(f[k], frames[0][k]) < 2e-2, k
-    assert rel_l2(frames[2]["shs"], frames[1]["shs"]) < 1e-5                   # atomic replay vs sorted reduction: same hits
+    if LEGACY:
+        assert rel_l2(frames[2]["shs"], frames[1]["shs"]) < 1e-5               # atomic replay vs sorted reduction: same hits
     tr.optix_context.set_option("hit_cap", 256)
 
 
@@ -622,8 +645,8 @@ def test_coincident_gaussians_are_ordered_by_index():
         ref[i, 0:3] += T * scenes.BG_DEFAULT; ref[i, 8] = T
     assert (ref[:, 4] > 0.05).sum() > 12                                       # most sampled rays composite coincident pairs
     for nw in (4, 8, 16):
-        a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw})
-        b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "bwd_mode": 2, "c4_waves": nw, "slab0_mm": 3000})
+        a = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "c4_waves": nw})
+        b = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 2, "c4_waves": nw, "slab0_mm": 3000})
         assert rel_l2(a["out"], b["out"]) < 1e-6, nw                           # other slabs, other collection order: same image
         got = a["out"].reshape(-1, 9)[rays]
         assert rel_l2(got, ref) < 2e-5, nw
@@ -646,7 +669,7 @@ def test_randomised_scenes_cr4_against_the_legacy_packet_kernel(seed):
         d = (d.reshape(-1, 3) @ np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], np.float32).T).reshape(H, W, 3).astype(np.float32)
     deg = int(r.integers(0, 4))
     dL = scenes.upstream_grad(H, W, seed=seed)
-    opts = {"fwd_mode": 2, "bwd_mode": 2, "slab0_mm": int(r.choice([2000, 8000, 24000, 100000])), "c4_waves": int(r.choice([4, 8])),
+    opts = {"fwd_mode": 2, "bwd_mode": 2 if LEGACY else 3, "slab0_mm": int(r.choice([2000, 8000, 24000, 100000])), "c4_waves": int(r.choice([4, 8])),
             "hit_cap": int(r.choice([16, 64, 256]))}
     a = run_hip(sc, o, d, deg, scenes.BG_DEFAULT, dL, opts=opts)
     b = run_hip(sc, o, d, deg, scenes.BG_DEFAULT, dL, opts={"fwd_mode": 0, "bwd_mode": 0})
@@ -694,7 +717,7 @@ def test_backward_twice_through_one_forward(s10k):
     sc, o, d, dL = s10k
     for place in (0,):
         tr = Tracer()
-        for k, v in {"fwd_mode": 2, "bwd_mode": 2, "defer_colour": 1, "reduce_mode": 2, "hit_cap": 256}.items():
+        for k, v in {"fwd_mode": 2, "bwd_mode": 2 if LEGACY else 3, "defer_colour": 1, "hit_cap": 256}.items():
             tr.optix_context.set_option(k, v)
         t = {k: torch.as_tensor(v, device="cuda:0").requires_grad_(True) for k, v in sc.items()}
         ro, rd = torch.as_tensor(o, device="cuda:0"), torch.as_tensor(d, device="cuda:0")

@@ -14,12 +14,16 @@ if torch.cuda.is_available():
     from tests.hip_util import run_hip, rel_l2, frac_outside
     from tests.test_hip_parity import _facing, oracle_run
 
-MODES = [{"fwd_mode": 2, "defer_colour": 1}, {"fwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 2}, {"fwd_mode": 2, "defer_colour": 1, "c4_waves": 8},
+from lidar_rt_amd import _capi
+LEGACY = _capi.has_legacy()       # the cross-check library (tests/test_legacy_crosscheck_gpu.py): colours inside the trace kernel, the sorted backward
+MODES = [{"fwd_mode": 2, "defer_colour": 1}, {"fwd_mode": 2, "defer_colour": 0}, {"fwd_mode": 0, "bwd_mode": 2 if LEGACY else 3}, {"fwd_mode": 2, "defer_colour": 1, "c4_waves": 8},
          {"fwd_mode": 2, "defer_colour": 1, "bwd_mode": 0}, {"fwd_mode": 0, "bwd_mode": 0}]      # the last two: the re-tracing backward replays the near rays itself
-IDS = ["collect4-defer", "collect4", "legacy-forward", "collect4-8waves", "collect4-retrace-bwd", "legacy-retrace-bwd"]
+IDS = ["collect4-defer", "collect4", "packet-forward", "collect4-8waves", "collect4-retrace-bwd", "packet-retrace-bwd"]
+_SEL_A = [i for i in range(4) if LEGACY or i != 1]
+_SEL_B = [i for i in (0, 1, 2, 4, 5) if LEGACY or i != 1]
 
 
-@pytest.mark.parametrize("mode", MODES[:4], ids=IDS[:4])
+@pytest.mark.parametrize("mode", [MODES[i] for i in _SEL_A], ids=[IDS[i] for i in _SEL_A])
 def test_known_answers_with_a_hit_below_the_near_threshold(mode):
     # the ray passes a little off the quads' centres: through a centre it would hit the shared edge of a quad's two triangles, and
     # the reference would then spend two K-buffer slots on one quad
@@ -57,7 +61,7 @@ def test_known_answers_with_a_hit_below_the_near_threshold(mode):
     np.testing.assert_allclose(h["accum"], fw["accum"], rtol=2e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("mode", MODES[:3] + MODES[4:], ids=IDS[:3] + IDS[4:])
+@pytest.mark.parametrize("mode", [MODES[i] for i in _SEL_B], ids=[IDS[i] for i in _SEL_B])
 def test_sensor_inside_the_geometry_matches_the_oracle(mode):
     """A sensor in the middle of dense clutter: about a third of the rays have a quad within 0.2 m.  Forward and (replay) backward
     against the oracle whose any-hit program is fed in ascending t, the realisation of the reference's order-dependent

@@ -57,7 +57,7 @@ for N in NS:
 import ctypes as C
 from lidar_rt_amd import _capi
 lib = _capi.load(); p = _capi.ptr
-for N in ((2, 4, 8) if os.environ.get("SLAB_OWNER", "1") == "1" else ()):
+for N in ((2, 4, 8) if os.environ.get("SLAB_OWNER", "0") == "1" and hasattr(lib, "lrt_owner_by_direction") else ()):      # (rounds 2-5: the owner exchange's device helpers, removed from the library in round 6)
     st = ShardedTracer.__new__(ShardedTracer); st.world = N; st.rank = 0
     st._rays_full = (torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev))
     a, b = column_slab(W, 0, N)
