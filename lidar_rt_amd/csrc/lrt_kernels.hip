@@ -187,7 +187,13 @@ struct lrt_state {
     float* nodes; float* nodes_aos; size_t cap_nodes; float4* pack; int no_pack, pack_valid, refine_ties;   // pack: (mean, opacity | scale, rot.xy | rot.zw) per primitive, 64-byte stride
     unsigned* bounds;    // 3 x 6 ordered-uint (min xyz, max xyz): read by this build / accumulated for the next / armed for the one after
     int bounds_sel, bounds_ready, lag_bounds;
-    int order_P;        // vals_b holds the sorted order of an unculled build of this many primitives (lrt_refit), else -1
+    int order_P;        // vals_b holds the Morton order of the last FULL sort of this many primitives (lrt_refit, carried builds, the cull index), else -1
+    // carried order (round 6): builds of an unchanged number of primitives keep the last full sort's permutation -- parameters move by an optimizer
+    // step between builds -- until it is `carry_max_age` builds old or more than carry_max_inv per mille of the neighbours in it are out of Morton
+    // order (counted by k_make_tree, published with the forward's status words)
+    int carry, carry_age, carry_max_age, carry_stale, carry_max_inv; unsigned carry_inv_last; unsigned* bounds_cur; int cell_shift; int last_build_culled;
+    // the cull index of ray-culled builds on the carried order (lrt_build.inc): per-primitive snapshot, per-range boxes, kept-range list, drift words
+    float4* idx_snap; float4* idx_box; uint32_t* idx_kept; unsigned* idx_drift; int idx_P, idx_rshift, idx_nranges;
     unsigned* cone; unsigned* cone_host; int P_built;   // ray-cone culled builds (lrt_build_for_rays): cone words, kept count
     // speculative sizing of the culled build: the sort and the tree are sized from the PREVIOUS culled build's kept count
     // (x1.25 + 4096), so that no read-back stalls the launch queue; cone_host = [kept, overflow] of the last build, valid after cone_ev
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ acc
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
     // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
     // [24] near rays found by the re-tracing backward, [25] its finished workgroups
-    if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;
+    if (i < 32 && i != 12 && i != 15) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;      // [15]: the build's order-decay counter, consumed by the epilogue
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
         for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -671,8 +677,13 @@ static void finish_tree_now(lrt_state* st, hipStream_t stream)
 }
 
 // Records + tree of `Pk` sorted slots (order = st->vals_b): the fused launch pair, or the level-by-level kernels of rounds 1-3.
+struct TreeExtras {      // what a build on the carried order adds to k_make_tree (all optional)
+    const uint32_t* kept_ranges = nullptr; int rshift = 0, P_src = 0; unsigned* cone = nullptr; float4* pack_out = nullptr;      // ray-culled build on the index
+    const unsigned* bounds = nullptr; int cell_shift = 0; unsigned* inv_count = nullptr;                                         // order-decay counter
+};
 static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, const float* scales, const float* rots, const float* opac, float mod,
-                                   const float4* pack, const unsigned* kept_ptr, bool records, hipStream_t stream, int* total_out, int* nl_out)
+                                   const float4* pack, const unsigned* kept_ptr, bool records, hipStream_t stream, int* total_out, int* nl_out,
+                                   const TreeExtras& ex = TreeExtras())
 {
     const int TB = 256;
     int nl, L, cnt[LRT_MAX_LEVELS], off[LRT_MAX_LEVELS];
@@ -693,7 +704,8 @@ static int launch_records_and_tree(lrt_state* st, int Pk, const float* means, co
         const int mt_blocks = Ppad > 0 ? (Ppad + MT_THREADS - 1) / MT_THREADS : 1;
         lrt_launch(st->lrec, k_make_tree, dim3(mt_blocks), dim3(MT_THREADS), 0, stream, Pk, (const uint32_t*)st->vals_b, means, scales, rots, opac, mod,
                            st->rec, pack, kept_ptr, st->nodes, st->nodes_aos, lay, st->fused_tree == 2 ? (unsigned*)nullptr : st->tree_top,
-                           kept_ptr ? st->cone_host : (unsigned*)nullptr);
+                           kept_ptr ? st->cone_host : (unsigned*)nullptr,
+                           ex.kept_ranges, ex.rshift, ex.P_src, ex.cone, ex.pack_out, ex.bounds, ex.cell_shift, ex.inv_count);
 #ifdef LRT_LEGACY
         if (st->fused_tree == 2 && L >= 4) lrt_launch(st->lrec, k_tree_top, dim3(1), dim3(1024), 0, stream, st->nodes, st->nodes_aos, lay);
         else
@@ -720,8 +732,9 @@ static int ensure_capacity(lrt_state* st, int P, hipStream_t stream)
     if (need <= st->capP) return LRT_OK;
     HIPCHK(hipStreamSynchronize(stream));
     size_t cap = need + need / 8 + 1024;
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->tree_top, st->idx_snap, st->idx_box, st->idx_kept};
     for (void* q : olds) (void)hipFree(q);
+    st->idx_snap = nullptr; st->idx_box = nullptr; st->idx_kept = nullptr; st->idx_P = -1; st->order_P = -1;
     st->nodes_aos = nullptr; st->pack = nullptr; st->tree_top = nullptr; st->tree_top_words = 0; st->tree_pending = 0;
     st->rec = st->aabb = st->nodes = nullptr; st->keys_a = st->keys_b = nullptr; st->vals_a = st->vals_b = nullptr; st->sort_tmp = nullptr;
     st->capP = 0;
@@ -794,6 +807,7 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
+    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
@@ -825,7 +839,8 @@ void lrt_destroy(lrt_state* st)
 {
     if (!st) return;
     DeviceGuard dg(st->device);
-    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone, st->tree_top};
+    void* olds[] = {st->rec, st->aabb, st->keys_a, st->keys_b, st->vals_a, st->vals_b, st->sort_tmp, st->nodes, st->nodes_aos, st->pack, st->bounds, st->ctrl, st->stats, st->ovf_list, st->cone, st->tree_top,
+                    st->idx_snap, st->idx_box, st->idx_kept, st->idx_drift};
     if (st->cone_host) { (void)hipHostFree(st->cone_host); (void)hipEventDestroy(st->cone_ev); }
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -843,7 +858,7 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
     if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
     const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
         {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec},
-        {"graph", st->graph_mode}, {"deferred_accum", st->deferred_accum}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
+        {"graph", st->graph_mode}, {"deferred_accum", st->deferred_accum}, {"carry_order", st->carry}, {"carry_age", st->carry_age}, {"carry_inversions_last", (int)st->carry_inv_last}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
     if (!strcmp(name, "cull_last")) {                        // primitives the last culled build kept (raw: also those a too small speculative size lost); -1 = none yet
         DeviceGuard dg(st->device);
@@ -895,6 +910,10 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
+    if (!strcmp(name, "carry_order")) { st->carry = value ? 1 : 0; st->carry_stale = 1; return LRT_OK; }   // 1 (default): builds of an unchanged number of primitives keep the last full sort's order (k_pack + k_make_tree, or the cull index for ray-culled builds); 0: every build sorts (the reference rebuilds its GAS from scratch)
+    if (!strcmp(name, "carry_max_age")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_age must be >= 0"); st->carry_max_age = value; return LRT_OK; }   // builds between two full sorts at most (32)
+    if (!strcmp(name, "carry_max_inv")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_inv must be >= 0"); st->carry_max_inv = value; return LRT_OK; }   // per mille of neighbour pairs out of Morton order (leaf-sized cells) that makes the next build sort again (20)
+    if (!strcmp(name, "carry_resort")) { st->carry_stale = 1; return LRT_OK; }   // the next build sorts
     if (!strcmp(name, "grads_prezeroed")) { st->grads_prezeroed = value ? 1 : 0; return LRT_OK; }   // see lrt_backward
     if (!strcmp(name, "deferred_accum")) { st->deferred_accum = value ? 1 : 0; st->acc_pending = 0; return LRT_OK; }   // see lrt_backward_accum
     if (!strcmp(name, "key32")) { st->key32 = value ? 1 : 0; return LRT_OK; }   // 0: 64-bit sort keys in every build
@@ -903,7 +922,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "colour_variant")) { st->colour_variant = value; return LRT_OK; }
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); if (value != 1 && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_tree=%d (the level-by-level / two-launch build) exists in the cross-check library only (-DLRT_LEGACY)", value); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
-    if (!strcmp(name, "fused_hist")) { st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
+    if (!strcmp(name, "fused_hist")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_hist=0 (a histogram launch of its own, k_rs_hist) exists in the cross-check library only (-DLRT_LEGACY)"); st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
@@ -937,7 +956,11 @@ long long lrt_forward_serial(lrt_state* st) { return st ? st->fwd_serial : -1; }
 int lrt_built_count(lrt_state* st)
 {
     if (!st || st->P < 0) return -1;
-    if (st->cone_pending && hipEventSynchronize(st->cone_ev) == hipSuccess) return (int)(st->cone_host[0] < (unsigned)st->P_built ? st->cone_host[0] : (unsigned)st->P_built);
+    if (st->last_build_culled && st->cone) {                     // primitives that passed the culled build's exact cone test (a diagnostic: waits for the device)
+        DeviceGuard dg(st->device);
+        unsigned n = 0u;
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&n, st->cone + 21, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) return (int)n;
+    }
     return st->P_built;
 }
 
@@ -947,6 +970,9 @@ int lrt_built_count(lrt_state* st)
 static int absorb_status(lrt_state* st)
 {
     st->fwd_pending = 0;
+    // order decay of the carried permutation, counted by the last build's k_make_tree: too many neighbour pairs out of Morton order -> sort again
+    st->carry_inv_last = (unsigned)st->hit_ovf_host[5];
+    if (st->P > 0 && (unsigned long long)st->carry_inv_last * 1000ull > (unsigned long long)st->carry_max_inv * (unsigned long long)st->P) st->carry_stale = 1;
     if (st->est_pending) {
         st->est_pending = 0;
         const unsigned n_hits = (unsigned)st->hit_ovf_host[1];
@@ -954,7 +980,7 @@ static int absorb_status(lrt_state* st)
         // a ray composited more hits than the record holds (that frame's backward re-traces): the following frames record with twice
         // the capacity; more hits than the dense key list holds: a longer key list
         if (st->hit_ovf_host[0] != 0 && st->hit_cap_auto && st->hit_cap < 4096 && st->pend_hw * (size_t)st->hit_cap * 2 < (1ull << 32)) st->hit_cap *= 2;
-        if (st->bwd_mode >= 2 && st->hit_keys && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;
+        if (st->bwd_mode >= 2 && st->key_cap > 0 && n_hits > st->key_cap && st->key_avg < st->hit_cap) st->key_avg *= 2;      // (the bucketed backward's record buffers are sized by key_cap too)
     }
     return st->hit_ovf_host[4] | st->hit_ovf_host[2];
 }
@@ -1108,6 +1134,72 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
     return bytes;
 }
 
+// The Morton order of ALL P primitives: bounds (first build of a state) -> k_morton (keys, packed parameter lines, the cull index's snapshot,
+// the sort's digit histograms) -> radix sort.  The result is st->vals_b; st->order_P = P.
+static int sort_all(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, hipStream_t stream)
+{
+    (void)fn;
+    const int TB = 256;
+    // three bounds sets rotate: this sort READS set s (the box of the previous sort's centres -- or, on the first build of a state
+    // and with option lag_bounds=0, the box k_bounds computes now), ACCUMULATES its own frame's box into set s+1 and ARMS set s+2
+    unsigned* bcur = st->bounds + 6 * (st->bounds_sel % 3);
+    unsigned* bacc = st->bounds + 6 * ((st->bounds_sel + 1) % 3);
+    unsigned* barm = st->bounds + 6 * ((st->bounds_sel + 2) % 3);
+    st->bounds_sel = (st->bounds_sel + 1) % 3;
+    if (!st->bounds_ready || !st->lag_bounds) {
+        static const unsigned init6[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};      // static: a recorded copy reads it when the graph runs
+        if (st->bounds_ready) HIPCHK(lrt_memcpy_async(st->lrec, bcur, init6, sizeof(init6), hipMemcpyHostToDevice, stream));   // lag_bounds=0: discard the carried box
+        int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;      // few blocks: the 6 atomics per block hit the same words
+        lrt_launch(st->lrec, k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
+    }
+    st->bounds_ready = 1;
+    st->bounds_cur = bcur;                                         // the grid of THIS order: k_make_tree's order-decay counter measures against it
+    float4* pack = st->no_pack ? nullptr : st->pack;
+    // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean primitive spacing; the order
+    // inside a cell is irrelevant); own onesweep (decided by the same rule below) and fused_hist: k_morton counts the sort's digit histograms on the way
+    int pbits = 1; while ((1ll << pbits) < (long long)P) pbits++;
+    int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
+    const bool own = st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode));      // below the limit rocPRIM's merge sort needs fewer launches
+    const bool hist_fused = st->fused_hist && own;
+    const bool key32 = st->key32 && own && LRT_SORT_LO_BIT == 31;
+    if (own) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
+    const int mthreads = hist_fused ? 1024 : TB;
+    int mb = (P + mthreads - 1) / mthreads; if (mb > (hist_fused ? 256 : 1024)) mb = hist_fused ? 256 : 1024;
+    lrt_launch(st->lrec, k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
+                       hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb : 63 - sb, key32 ? 32 : 63, key32 ? 1 : 0, st->idx_snap);
+    if (own) {
+        // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
+        uint64_t* kr = nullptr; uint32_t* vr = nullptr;
+        if (key32) {                                               // k_morton wrote 32-bit keys (code >> 31) into the key buffer
+            uint32_t* kr32 = nullptr;
+            HIPCHK((rs_sort<uint32_t, true, 8>(st->sort_build, reinterpret_cast<uint32_t*>(st->keys_a), reinterpret_cast<uint32_t*>(st->keys_b), st->vals_a, st->vals_b,
+                                               (unsigned)P, 32 - sb, 32, stream, &kr32, &vr, hist_fused, st->lrec, nullptr)));
+        } else
+        HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)P, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec, nullptr)));
+        if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
+    } else {
+        size_t tmp = st->sort_tmp_bytes;
+        int sort_bits = ((pbits + st->morton_extra + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
+        HIPCHK(lrt_rec_flush(st->lrec, stream));                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
+        HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)P, 63 - sort_bits, 63, stream));
+    }
+    st->order_P = P; st->carry_age = 0; st->carry_stale = 0;
+    st->pack_valid = pack ? 1 : 0;
+    // leaf-sized Morton cells for the order-decay counter: the top log2(P) - 3 bits of the 63-bit code (8 primitives per cell on average)
+    st->cell_shift = 63 - (pbits > 6 ? pbits - 3 : 3);
+    if (st->idx_snap) {                                            // this state builds ray-culled structures: the range boxes of the cull index, from the fresh snapshot
+        int rs = 5; while (rs < 9 && ((long long)P >> rs) > 2048) rs++;
+        st->idx_rshift = rs; st->idx_nranges = (int)(((long long)P + (1 << rs) - 1) >> rs); st->idx_P = P;
+        lrt_launch(st->lrec, k_index_boxes, dim3((st->idx_nranges + 3) / 4), dim3(256), 0, stream, P, rs, (const uint32_t*)st->vals_b, (const float4*)st->idx_snap, st->idx_box, st->idx_drift);
+    }
+    return LRT_OK;
+}
+
+// One build.  The ORDER of the primitives is the Morton order of the last full sort of these P primitives (the carried order: parameters move
+// by an optimizer step between builds), sorted again when P changed, when the order is `carry_max_age` builds old or has decayed (k_make_tree
+// counts neighbours out of order), or with option carry_order = 0 (every build sorts: what the reference's full GAS rebuild corresponds to).
+//   all rays:    [k_morton + sort | k_pack] -> k_make_tree (records + tree, gathering the packed lines in that order)
+//   ray-culled:  [k_morton + sort + k_index_boxes | k_drift] -> k_cone_cull (kept ranges of the order) -> k_make_tree over the kept ranges
 static int build_impl(const char* fn, lrt_state* st, int P, const float* means, const float* scales, const float* rots,
                       const float* opac, float mod, int n_rays, const float* ray_o, const float* ray_d, void* stream_, int slab_H = 0, int slab_W = 0)
 {
@@ -1120,143 +1212,96 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_capacity(st, P, stream);
     if (rc) return rc;
-    st->P = -1; st->cone_flag_live = 0; st->order_P = -1;
+    st->P = -1; st->cone_flag_live = 0;
     ScopedTimer tm(st, 0, stream);
     const int TB = 256;
-    int Pk = P;                                                  // primitives that enter the LBVH
+    int Pk = P;                                                  // slots of the LBVH
     const unsigned* cone_kept = nullptr; const float4* pack_used = nullptr;
+    TreeExtras ex;
+    const bool culled = n_rays > 0 && P > 0;
     if (P > 0) {
-        unsigned* cone = nullptr;
-        if (n_rays > 0) {                                        // cull against the cone around the given rays
+        if (st->fwd_pending && hipEventQuery(st->hit_ev) == hipSuccess) (void)absorb_status(st);      // (the order-decay count of the last build, when it has arrived; error bits stay until a call reports them)
+        if (culled && !st->idx_snap) {                           // first ray-culled build of this state (or after the buffers grew): the cull index's buffers
+            HIPCHK(hipMalloc(&st->idx_snap, st->capP * sizeof(float4)));
+            HIPCHK(hipMalloc(&st->idx_box, (st->capP / 32 + 2) * 2 * sizeof(float4)));
+            HIPCHK(hipMalloc(&st->idx_kept, (st->capP / 32 + 2) * sizeof(uint32_t)));
+            if (!st->idx_drift) { HIPCHK(hipMalloc(&st->idx_drift, 4 * sizeof(unsigned))); HIPCHK(hipMemsetAsync(st->idx_drift, 0, 4 * sizeof(unsigned), stream)); }
+            st->idx_P = -1;
+        }
+        bool carried = st->carry && st->order_P == P && st->carry_age < st->carry_max_age && !st->carry_stale;
+        if (culled && st->idx_P != P) carried = false;           // (an order without a snapshot: sorted before this state's first culled build)
+        if (!carried) { rc = sort_all(fn, st, P, means, scales, rots, opac, stream); if (rc) return rc; }
+        else st->carry_age++;
+        float4* pack = st->no_pack ? nullptr : st->pack;
+        if (!culled) {
+            if (carried && pack) { lrt_launch(st->lrec, k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack); st->pack_valid = 1; }
+            else if (carried) st->pack_valid = 0;
+            pack_used = pack;
+            if (st->carry) { ex.bounds = st->bounds_cur; ex.cell_shift = st->cell_shift; ex.inv_count = st->ctrl + 15; }
+        } else {
             if (!st->cone) {
                 HIPCHK(hipMalloc(&st->cone, 32 * sizeof(unsigned))); HIPCHK(hipMemset(st->cone, 0, 32 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
                 HIPCHK(hipEventCreateWithFlags(&st->cone_ev, hipEventDisableTiming));
             }
-            cone = st->cone;
+            unsigned* cone = st->cone;
             if (st->cone_pending) {                              // kept count of the previous (speculatively sized) culled build
-                HIPCHK(hipEventSynchronize(st->cone_ev));        // copied right after its k_morton: long done
+                HIPCHK(hipEventSynchronize(st->cone_ev));        // stored by its k_make_tree: long done
                 st->cone_pending = 0;
                 st->cone_have_prev = (st->cone_host[1] == 0u);   // after an overflow the next build reads the count back again
                 st->cone_prev = st->cone_host[0]; st->cone_seen = 1;
             }
-            lrt_launch(st->lrec, k_cone_all, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W);      // one workgroup for any ray set (round 6: the three-launch path for > 131072 rays is gone)
-        }
-        // three bounds sets rotate: this build READS set s (the box of the previous build's centres -- or, on the first build of a state
-        // and with option lag_bounds=0, the box k_bounds computes now), ACCUMULATES its own frame's box into set s+1 and ARMS set s+2
-        unsigned* bcur = st->bounds + 6 * (st->bounds_sel % 3);
-        unsigned* bacc = st->bounds + 6 * ((st->bounds_sel + 1) % 3);
-        unsigned* barm = st->bounds + 6 * ((st->bounds_sel + 2) % 3);
-        st->bounds_sel = (st->bounds_sel + 1) % 3;
-        if (!st->bounds_ready || !st->lag_bounds) {
-            static const unsigned init6[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};      // static: a recorded copy reads it when the graph runs
-            if (st->bounds_ready) HIPCHK(lrt_memcpy_async(st->lrec, bcur, init6, sizeof(init6), hipMemcpyHostToDevice, stream));   // lag_bounds=0: discard the carried box
-            int gb = (P + TB - 1) / TB; if (gb > 512) gb = 512;      // few blocks: the 6 atomics per block hit the same words
-            lrt_launch(st->lrec, k_bounds, dim3(gb), dim3(TB), 0, stream, P, means, opac, bcur, scales, (const unsigned*)nullptr);
-        }
-        st->bounds_ready = 1;
-        float4* pack = (cone || st->no_pack) ? nullptr : st->pack;   // the culled build compacts: it keeps the direct gathers
-        // The sort and the tree of a culled build are sized by the kept count.  Reading it back stalls the launch queue (the
-        // host cannot run ahead), so from the second culled build of the same P on the size is SPECULATIVE: 1.25 x the previous
-        // count + 4096; the unused tail holds sentinel keys (sorted last, turned into padding by k_make_records) and the actual count
-        // comes back asynchronously for the next build.  Kept primitives that did not fit raise error code 8 in the next forward.
-        unsigned keep_cap = (unsigned)P;
-        bool spec = false, hist_fused = false, key32 = false; const unsigned* sort_nv = nullptr; int own_limit = LRT_BUILD_MERGE_LIMIT;
-        // The library's own rule trusts the previous build's count, i.e. assumes that consecutive culled builds see about the same ray set.  A
-        // caller whose ray sets change (training frames drawn at random from a drive) says what it knows instead (option cull_next): a capacity
-        // learnt from an earlier build for THESE rays, or 0 = unknown, read the count back.
-        if (cone && st->cull_next > 0) {
-            if ((unsigned long long)st->cull_next < (unsigned long long)P) { keep_cap = (unsigned)(st->cull_next < 64 ? 64 : st->cull_next); spec = true; }
-        } else if (cone && st->cull_next < 0 && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
-            unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess
-                                                        : (st->cone_prev + st->cone_prev / 4 + 4096ull);
-            if (gsz < (unsigned long long)P) { keep_cap = (unsigned)(gsz < 64 ? 64 : gsz); spec = true; }
-            st->cull_guess = 0;
-        }
-        st->cull_next = -1;
-        if (cone) {
-            // a speculatively sized culled build knows the number of sorted keys (keep_cap) before the launch: its own sort's digit histograms
-            // are counted by k_morton_cull and its keys are 32 bits wide, like the unculled build's (the read-back path sizes the sort after
-            // the kernel: it keeps the histogram launch and 64-bit keys)
-            int sb_ = 0;
-            if (spec) {
-                int pb_ = 1; while ((1ll << pb_) < (long long)keep_cap) pb_++;
-                sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
-                // with the histogram counted by k_morton_cull and no sentinel fill the own sort beats rocPRIM's merge sort well below the limit of
-                // the unculled build (a rank of 8 on S1M sorts 117 k keys: build 0.128 -> 0.115 ms)
-                own_limit = 32768;
-                const bool own = st->own_sort == 1 || (st->own_sort == 2 && ((int)keep_cap >= own_limit || st->graph_mode));
-                hist_fused = st->fused_hist && own;
-                key32 = st->key32 && own && LRT_SORT_LO_BIT == 31;
-                if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
-                // the slots behind the kept keys must sort last: the own sort's first pass reads them as all-ones by the kept count (no fill
-                // launch); rocPRIM's sort needs the sentinel keys in memory
-                if (!(own && hist_fused)) HIPCHK(lrt_memset_async(st->lrec, st->keys_a, 0xff, (size_t)keep_cap * (key32 ? sizeof(uint32_t) : sizeof(uint64_t)), stream));
-                else sort_nv = cone + 10;
+            if (carried) {                                       // how far has anything moved since the index's snapshot?  (a fresh index: nothing, k_index_boxes said so)
+                int db = (P + TB - 1) / TB; if (db > 1024) db = 1024;
+                lrt_launch(st->lrec, k_drift, dim3(db), dim3(TB), 0, stream, P, means, scales, opac, (const float4*)st->idx_snap, st->idx_drift);
             }
-            lrt_launch(st->lrec, k_morton_cull, dim3((P + 256 * MC_ITEMS - 1) / (256 * MC_ITEMS)), dim3(256), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, cone, keep_cap, rots, st->no_pack ? (float4*)nullptr : st->pack,
-                       hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb_ : 63 - sb_, key32 ? 32 : 63, key32 ? 1 : 0);
-        } else {
-            // own onesweep next (decided below by the same rule) and fused_hist: k_morton counts the sort's digit histograms on the way
-            int pb_ = 1; while ((1ll << pb_) < (long long)P) pb_++;
-            int sb_ = pb_ + st->morton_extra; if (sb_ > 32) sb_ = 32; if (sb_ > 63 - LRT_SORT_LO_BIT) sb_ = 63 - LRT_SORT_LO_BIT; if (sb_ < 8) sb_ = 8;
-            hist_fused = st->fused_hist && (st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode)));
-            if (hist_fused) HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
-            key32 = st->key32 && (st->own_sort == 1 || (st->own_sort == 2 && (P >= LRT_BUILD_MERGE_LIMIT || st->graph_mode))) && LRT_SORT_LO_BIT == 31;
-            const int mthreads = hist_fused ? 1024 : TB;
-            int mb = (P + mthreads - 1) / mthreads; if (mb > (hist_fused ? 256 : 1024)) mb = hist_fused ? 256 : 1024;
-            lrt_launch(st->lrec, k_morton, dim3(mb), dim3(mthreads), 0, stream, P, means, opac, bcur, bacc, barm, st->keys_a, st->vals_a, scales, rots, pack,
-                               hist_fused ? st->sort_build.hist : (unsigned*)nullptr, key32 ? 32 - sb_ : 63 - sb_, key32 ? 32 : 63, key32 ? 1 : 0);
-        }
-        if (cone) {
-            // the kept count travels to the host for the next build's sizing: k_make_tree stores it into the pinned words itself when the build
-            // is speculative and the fused tree kernel runs; otherwise an 8-byte copy behind k_morton_cull
-            if (!(spec && st->fused_tree)) HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            // The tree of a culled build is sized by the slots of the kept ranges.  Reading the count back stalls the launch queue (the host cannot run
+            // ahead), so from the second culled build of the same P on the size is SPECULATIVE: 1.25 x the previous count + 4096; the unused tail is
+            // padding and the actual count comes back asynchronously for the next build.  Kept ranges that did not fit raise error code 8 in the
+            // next forward.  The library's own rule trusts the previous build's count, i.e. assumes that consecutive culled builds see about the same
+            // ray set; a caller whose ray sets change (training frames drawn at random from a drive) says what it knows instead (option cull_next): a
+            // capacity learnt from an earlier build for THESE rays, or 0 = unknown, read the count back.
+            const int rs = st->idx_rshift;
+            const unsigned all_slots = (unsigned)st->idx_nranges << rs;
+            unsigned keep_cap = all_slots; bool spec = false;
+            if (st->cull_next > 0) {
+                if ((unsigned long long)st->cull_next < (unsigned long long)all_slots) { keep_cap = (unsigned)(st->cull_next < 64 ? 64 : st->cull_next); spec = true; }
+            } else if (st->cull_next < 0 && st->spec_cull && st->cone_have_prev && st->cone_prev_P == P) {
+                unsigned long long gsz = st->cull_guess > 0 ? (unsigned long long)st->cull_guess : (st->cone_prev + st->cone_prev / 4 + 4096ull);
+                if (gsz < (unsigned long long)all_slots) { keep_cap = (unsigned)(gsz < 64 ? 64 : gsz); spec = true; }
+                st->cull_guess = 0;
+            }
+            st->cull_next = -1;
+            keep_cap = ((keep_cap + (1u << rs) - 1u) >> rs) << rs;       // whole ranges
+            if (keep_cap > all_slots) keep_cap = all_slots;
+            lrt_launch(st->lrec, k_cone_cull, dim3(1), dim3(1024), 0, stream, n_rays, ray_o, ray_d, cone, slab_H, slab_W, st->idx_nranges, rs, (const float4*)st->idx_box, st->idx_drift,
+                       st->idx_kept, keep_cap);
             st->cone_prev_P = P;
             if (spec) {
-                st->cone_ev_due = 1;                             // recorded by the caller once this call's launches have been issued
+                st->cone_ev_due = 1;                             // recorded by the caller once this call's launches have been issued (k_make_tree stores the count into the pinned words)
                 st->cone_pending = 1;
                 Pk = (int)keep_cap;
             } else {                                             // first culled build of this size: one 8-byte read-back
+                HIPCHK(lrt_memcpy_async(st->lrec, st->cone_host, cone + 10, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
                 HIPCHK(lrt_rec_flush(st->lrec, stream));          // (the recorded launches must run before the host can read their result)
                 HIPCHK(hipStreamSynchronize(stream));
                 Pk = (int)st->cone_host[0];
-                if (Pk < 0 || Pk > P) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
+                if (Pk < 0 || (unsigned)Pk > all_slots) LRT_FAIL(LRT_ERR_STATE, "%s: culling returned a bad count %d", fn, Pk);
                 st->cone_prev = (unsigned)Pk; st->cone_have_prev = 1; st->cone_seen = 1;
             }
+            st->cone_flag_live = spec ? 1 : 0;
+            cone_kept = spec ? cone + 10 : nullptr;
+            pack_used = nullptr;                                 // a culled build gathers the few kept primitives from the four parameter arrays directly
+            ex.kept_ranges = st->idx_kept; ex.rshift = rs; ex.P_src = P; ex.cone = cone; ex.pack_out = pack;
+            st->pack_valid = pack ? 1 : 0;                       // k_make_tree writes the packed line of every primitive this build can hit
         }
-        st->cone_flag_live = spec ? 1 : 0;
-        if (Pk > 0) {
-            size_t tmp = st->sort_tmp_bytes;
-            // Only the top bits of the 63-bit code order the primitives: log2(P) + 4 bits (cells ~16x finer than the mean
-            // primitive spacing; the order inside a cell is irrelevant), rounded up to whole 8-bit onesweep passes, at most 32.
-            int pbits = 1; while ((1ll << pbits) < (long long)Pk) pbits++;
-            int sort_bits = ((pbits + st->morton_extra + 7) / 8) * 8; if (sort_bits > 63 - LRT_SORT_LO_BIT) sort_bits = 63 - LRT_SORT_LO_BIT; if (sort_bits < 8) sort_bits = 8;
-            if (st->own_sort == 1 || (st->own_sort == 2 && (Pk >= own_limit || st->graph_mode))) {      // below the limit rocPRIM's merge sort needs fewer launches (replayed from a graph the launches cost nothing: own sort)
-                // own onesweep: exactly log2(P) + 4 bits, 8 per pass, no fills; the result lands in (keys_b, vals_b) after a pointer swap
-                int sb = pbits + st->morton_extra; if (sb > 32) sb = 32; if (sb > 63 - LRT_SORT_LO_BIT) sb = 63 - LRT_SORT_LO_BIT; if (sb < 8) sb = 8;
-                HIPCHK(rs_reserve(st->sort_build, st->capP, 8, stream));
-                uint64_t* kr = nullptr; uint32_t* vr = nullptr;
-                if (key32) {                                               // k_morton wrote 32-bit keys (code >> 31) into the key buffer
-                    uint32_t* kr32 = nullptr;
-                    HIPCHK((rs_sort<uint32_t, true, 8>(st->sort_build, reinterpret_cast<uint32_t*>(st->keys_a), reinterpret_cast<uint32_t*>(st->keys_b), st->vals_a, st->vals_b,
-                                                       (unsigned)Pk, 32 - sb, 32, stream, &kr32, &vr, hist_fused, st->lrec, sort_nv)));
-                } else
-                HIPCHK((rs_sort<uint64_t, true, 8>(st->sort_build, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (unsigned)Pk, 63 - sb, 63, stream, &kr, &vr, hist_fused, st->lrec, sort_nv)));
-                if (vr != st->vals_b) { uint64_t* tk = st->keys_a; st->keys_a = st->keys_b; st->keys_b = tk; uint32_t* tv = st->vals_a; st->vals_a = st->vals_b; st->vals_b = tv; }
-            } else {
-                HIPCHK(lrt_rec_flush(st->lrec, stream));                    // rocPRIM launches by itself: what was recorded so far goes first, the rest of the call is eager
-                HIPCHK(rocprim::radix_sort_pairs<lrt_build_sort_cfg>(st->sort_tmp, tmp, st->keys_a, st->keys_b, st->vals_a, st->vals_b, (size_t)Pk, 63 - sort_bits, 63, stream));
-            }
-        }
-        cone_kept = spec ? cone + 10 : nullptr; pack_used = pack;
     }
     int nl = 0, total = 0;
-    rc = launch_records_and_tree(st, Pk, means, scales, rots, opac, mod, (const float4*)pack_used, (const unsigned*)cone_kept, P > 0, stream, &total, &nl);
+    rc = launch_records_and_tree(st, Pk, means, scales, rots, opac, mod, (const float4*)pack_used, (const unsigned*)cone_kept, P > 0, stream, &total, &nl, ex);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     st->P = P; st->P_built = Pk; st->mod = mod; st->n_nodes = total; st->n_leaves = nl;
-    st->pack_valid = (P > 0 && !st->no_pack) ? 1 : 0;     // k_morton / k_morton_cull wrote the packed lines of every primitive that can be hit
-    st->order_P = (n_rays == 0 && P > 0) ? P : -1;
+    if (P == 0) { st->pack_valid = 0; st->order_P = -1; }
+    st->last_build_culled = culled ? 1 : 0;
     return LRT_OK;
 }
 
@@ -1306,7 +1351,7 @@ int lrt_refit(lrt_state* st, int P, const float* means, const float* scales, con
 }
 static int refit_impl(lrt_state* st, int P, const float* means, const float* scales, const float* rots, const float* opac, float mod, void* stream_)
 {
-    if (P <= 0 || st->P != P || st->P_built != P || st->order_P != P)
+    if (P <= 0 || st->P != P || st->P_built != P || st->order_P != P || st->last_build_culled)
         LRT_FAIL(LRT_ERR_STATE, "lrt_refit: needs a preceding lrt_build of the same %d primitives (not a ray-culled one)", P);
     if (!means || !scales || !rots || !opac) LRT_FAIL(LRT_ERR_ARG, "lrt_refit: null parameter pointer");
     DeviceGuard dg(st->device);

@@ -511,6 +511,9 @@ def training_step(scene: GaussianScene, frames: RangeFrames, frame, iteration: i
             bad = _rnd.sharded.verify_step()
             if bad is not None:
                 from ._capi import LrtError
+                for g_ in scene.gaussians_assets:                          #  the incomplete gradients of attempt 2 must not wait in .grad for a
+                    for p_ in g_._params().values():                       # caller that catches this and runs the next backward on top of them
+                        p_.grad = None
                 raise LrtError(f"sharded training step {iteration}: incomplete results on a rank in two attempts ({bad[0]}; per-rank words {bad[1]}); "
                                "the optimizer step was NOT taken, the parameters are those of the previous iteration.  " + _rnd.sharded._STATUS_HELP)
     with torch.no_grad():

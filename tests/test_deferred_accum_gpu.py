@@ -75,7 +75,10 @@ def test_deferred_weights_equal_the_oracle_and_the_forward_atomics_on_s10k(s10k,
     h = _run(sc, o, d, 3, scenes.BG_DEFAULT, dL, deferred=True, opts=opts)
     assert not h["accum_after_forward"].any(), "a deferred training forward must leave accum all-zero"
     assert exact["accum_after_forward"].any()
-    np.testing.assert_array_equal(h["out"], exact["out"])                         # the image does not know about the option
+    if "hit_cap" in opts:      # hits beyond the record reach the colour pass through an overflow list in arrival order: equal to rounding
+        np.testing.assert_allclose(h["out"], exact["out"], rtol=2e-6, atol=1e-7)
+    else:
+        np.testing.assert_array_equal(h["out"], exact["out"])                     # the image does not know about the option
     assert frac_outside(h["accum"], fw["accum"], 1e-4) <= 1e-3 and rel_l2(h["accum"], fw["accum"]) < 1e-5, what
     assert rel_l2(h["accum"], exact["accum"]) < 2e-6, what                          # the same weights, added in another order
     np.testing.assert_array_equal(h["accum"] > 0, exact["accum"] > 0)               # the exact touched set (the sharded exchange's mask)
@@ -133,10 +136,14 @@ def test_deferred_weights_on_s200k_and_through_the_renderer():
     sc = scenes.make_scene(200_000, radius_scale=0.5); o, d = scenes.kitti_rays(32, 512)
     dL = scenes.upstream_grad(32, 512)
     fw, _ = _oracle(sc, o, d, 3, scenes.BG_DEFAULT, dL)
+    exact = _run(sc, o, d, 3, scenes.BG_DEFAULT, dL, deferred=False)
     for opts in ({}, {"bwd_mode": 0}):
         h = _run(sc, o, d, 3, scenes.BG_DEFAULT, dL, deferred=True, opts=opts)
         assert not h["accum_after_forward"].any()
-        assert frac_outside(h["accum"], fw["accum"], 1e-4) <= 2e-3 and rel_l2(h["accum"], fw["accum"]) < 1e-4, opts
+        # against the oracle: the large scenes' threshold events (a hit composited by one implementation and not by the other), like the
+        # exact-at-forward weights; against those weights themselves: the same hits (the packet kernel of bwd_mode 0 decides a few knife edges its own way)
+        assert frac_outside(h["accum"], fw["accum"], 1e-4) <= 2e-3 and rel_l2(h["accum"], fw["accum"]) < 2e-3, opts
+        assert rel_l2(h["accum"], exact["accum"]) < (2e-6 if not opts else 2e-3), opts
     # renderer.raytracing with the module switch: train.py's read of accum_gaussian_weight behind loss.backward()
     import types
     from lidar_rt_amd import renderer

@@ -398,7 +398,7 @@ def test_bucketed_backward_against_the_sorted_one_on_awkward_index_layouts():
             np.testing.assert_array_equal(got["out"], ref["out"])
             for k in GRADS:
                 assert np.isfinite(got["grads"][k]).all()
-                assert rel_l2(got["grads"][k], ref["grads"][k]) < 5e-6, (len(sc["means"]), H, W, k)     # other summation order inside a Gaussian's run
+                assert rel_l2(got["grads"][k], ref["grads"][k]) < (5e-6 if LEGACY else 5e-5), (len(sc["means"]), H, W, k)     # other summation order inside a Gaussian's run (product: the packet kernel's own hit distances too)
                 assert ((got["grads"][k] != 0) == (ref["grads"][k] != 0)).mean() > 0.9999              # rows of untouched Gaussians are zeros, not leftovers
 
 

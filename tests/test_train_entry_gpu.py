@@ -1,0 +1,67 @@
+"""`python -m lidar_rt_amd.train --data DIR` (the train.py-shaped loop on a file-backed sequence) on the KITTI-360-dynamic shape: 66 x 1030
+range images, a background and 8 rigid actors with a pose per frame (BASELINE configs[3]; tools/make_sequence.py renders the sequence).
+50 iterations from disk, then a second run resumed from the iteration-25 checkpoint."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path):
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def test_fifty_iterations_from_disk_and_a_resume_from_the_checkpoint(tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_sequence
+    from lidar_rt_amd import sequence, train, training
+    data = str(tmp_path / "seq")
+    meta = make_sequence.make("kitti360_dynamic", data, n_frames=6, scale=0.04)
+    assert (meta["height"], meta["width"]) == (66, 1030) and meta["dynamic"] and meta["n_actors"] == 8
+    seq = sequence.load_sequence(data, "cuda:0")
+    valid = float(torch.stack([seq.frames.get_mask(f).float().mean() for f in seq.train_frames]).mean())
+    assert 0.3 < valid <= 1.0, valid                                       # the rendered ground truth has returns
+    common = ["--data", data, "--log-every", "5", "--save-every", "25", "--max-points", "60000", "--opt", "lambda_cd=0.01"]
+    run = lambda out, extra: subprocess.run([sys.executable, "-m", "lidar_rt_amd.train", "--out", out] + common + extra, cwd=REPO, capture_output=True,
+                                            text=True, timeout=1500)
+    a = run(str(tmp_path / "a"), ["--iters", "50"])
+    assert a.returncode == 0, a.stdout[-2000:] + a.stderr[-3000:]
+    rows = [json.loads(l) for l in a.stdout.splitlines() if l.startswith("{")]
+    assert rows[-1]["iteration"] == 50 and rows[-1]["loss"] < 0.8 * rows[0]["loss"], rows                    # it trains
+    for it in (25, 50):
+        assert os.path.exists(tmp_path / "a" / f"chkpnt{it}.pth")
+    params25, it25 = _load(tmp_path / "a" / "chkpnt25.pth")
+    assert it25 == 25 and len(params25) == 9 and len(params25[0]) == 12                                  # background + 8 actors, the reference's 12-tuple
+    # restoring the checkpoint reproduces every tensor and the optimizer state bit for bit
+    opt = training.default_options()
+    scene = sequence.scene_from_sequence(seq, max_points=60000, seed=0)
+    scene.training_setup(opt)
+    scene.restore(_load(tmp_path / "a" / "chkpnt25.pth")[0], opt)
+    for g, saved in zip(scene.gaussians_assets, params25):
+        back = g.capture()
+        for i in (1, 2, 3, 4, 5, 6, 8, 9):
+            assert torch.equal(back[i].detach().cpu(), saved[i].detach().cpu()), i
+        for k, st in saved[10]["state"].items():
+            for n in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(back[10]["state"][k][n].cpu(), st[n].cpu())
+    # a second process resumes at 26 and runs to 50: same frames, same densification draws; the step's float sums carry atomic-order noise
+    b = run(str(tmp_path / "b"), ["--iters", "50", "--resume", str(tmp_path / "a" / "chkpnt25.pth")])
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-3000:]
+    rows_b = [json.loads(l) for l in b.stdout.splitlines() if l.startswith("{")]
+    assert [r["iteration"] for r in rows_b] == [r["iteration"] for r in rows if r["iteration"] > 25]
+    assert [r["frame"] for r in rows_b] == [r["frame"] for r in rows if r["iteration"] > 25]
+    assert [r["points"] for r in rows_b] == [r["points"] for r in rows if r["iteration"] > 25]
+    for ra, rb in zip([r for r in rows if r["iteration"] > 25], rows_b):
+        assert abs(ra["loss"] - rb["loss"]) <= 2e-3 * abs(ra["loss"]), (ra, rb)
+    pa, pb = _load(tmp_path / "a" / "chkpnt50.pth")[0], _load(tmp_path / "b" / "chkpnt50.pth")[0]
+    for ga, gb in zip(pa, pb):
+        for i in (1, 4, 6):                                                # positions, scales, opacities
+            x, y = ga[i].detach().double(), gb[i].detach().double()
+            assert float((x - y).norm() / x.norm().clamp_min(1e-30)) < 1e-3, i
