@@ -220,6 +220,7 @@ struct lrt_state {
     float* dbg; size_t dbg_floats;
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
+    unsigned* inv_words; // 64 words: neighbour pairs of the carried build order found out of Morton order (k_make_tree), summed and cleared by the forward's epilogue
     unsigned* ctrl;      // 16 words zeroed by ONE memset per forward: [0..7] tile queues, [8] hit_ovf, [9] hit_count, [10] err_flag, [11] ovf_count
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;   // deferred colour: composited hits beyond hit_cap (ray, gidx, weight)
     size_t hit_rays_cap; int hit_cap, hit_cap_alloc; int hit_H, hit_W; int hits_valid; int replay_enabled; int hit_cap_auto; int key_avg, key_avg_alloc;   // key_avg: dense (gidx, id) key list sized for this many composited hits per ray
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ acc
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
     // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
     // [24] near rays found by the re-tracing backward, [25] its finished workgroups
-    if (i < 32 && i != 12 && i != 15) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;      // [15]: the build's order-decay counter, consumed by the epilogue
+    if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;      // ([32..95]: the build's order-decay counters, summed and cleared by the epilogue)
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
         for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -811,7 +812,7 @@ lrt_state* lrt_create(int device)
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
-    if (hipMalloc(&st->ctrl, 32 * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, 32 * sizeof(unsigned)) != hipSuccess ||
+    if (hipMalloc(&st->ctrl, (32 + 64) * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, (32 + 64) * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
         hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
@@ -819,7 +820,7 @@ lrt_state* lrt_create(int device)
         delete st->timers; delete st;
         return nullptr;
     }
-    st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9;
+    st->tile_counter = st->ctrl; st->hit_ovf = reinterpret_cast<int*>(st->ctrl + 8); st->hit_count = st->ctrl + 9; st->inv_words = st->ctrl + 32;
     st->err_flag = reinterpret_cast<int*>(st->ctrl + 10); st->ovf_count = st->ctrl + 11; st->ovf_cap = 1u << 20;
     for (int i = 0; i < 8; i++) st->hit_ovf_host[i] = 0;
     st->spec_bwd = 1; st->spec_margin = 65536; st->refine_ties = 1;
@@ -958,8 +959,8 @@ int lrt_built_count(lrt_state* st)
     if (!st || st->P < 0) return -1;
     if (st->last_build_culled && st->cone) {                     // primitives that passed the culled build's exact cone test (a diagnostic: waits for the device)
         DeviceGuard dg(st->device);
-        unsigned n = 0u;
-        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&n, st->cone + 21, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) return (int)n;
+        unsigned w[64];
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(w, st->cone + 32, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) { unsigned n = 0u; for (unsigned v : w) n += v; return (int)n; }
     }
     return st->P_built;
 }
@@ -1237,10 +1238,10 @@ static int build_impl(const char* fn, lrt_state* st, int P, const float* means, 
             if (carried && pack) { lrt_launch(st->lrec, k_pack, dim3((P + TB - 1) / TB), dim3(TB), 0, stream, P, means, scales, rots, opac, pack); st->pack_valid = 1; }
             else if (carried) st->pack_valid = 0;
             pack_used = pack;
-            if (st->carry) { ex.bounds = st->bounds_cur; ex.cell_shift = st->cell_shift; ex.inv_count = st->ctrl + 15; }
+            if (st->carry) { ex.bounds = st->bounds_cur; ex.cell_shift = st->cell_shift; ex.inv_count = st->inv_words; }
         } else {
             if (!st->cone) {
-                HIPCHK(hipMalloc(&st->cone, 32 * sizeof(unsigned))); HIPCHK(hipMemset(st->cone, 0, 32 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
+                HIPCHK(hipMalloc(&st->cone, 96 * sizeof(unsigned))); HIPCHK(hipMemset(st->cone, 0, 96 * sizeof(unsigned))); HIPCHK(hipHostMalloc((void**)&st->cone_host, 2 * sizeof(unsigned)));
                 HIPCHK(hipEventCreateWithFlags(&st->cone_ev, hipEventDisableTiming));
             }
             unsigned* cone = st->cone;

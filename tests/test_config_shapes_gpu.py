@@ -59,7 +59,9 @@ def test_waymo_static_2m_matches_oracle_within_the_floor():
     f64 = oracle_pair(sc, o, d, 3, scenes.BG_DEFAULT, dL, "f64")
     h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
     np.testing.assert_allclose(h["out"][..., 4] + h["out"][..., 8], 1.0, atol=2e-5)             # energy per ray
-    parity_report("waymo_static_2m", h, f32, f64, extra={
+    from tests.event_gate import event_masked_gate
+    event_masked_gate("waymo_static_2m", sc, o, d, 3, scenes.BG_DEFAULT, dL, f32[0], f64[0])
+    parity_report("waymo_static_2m", h, f32, f64, f64_k=None, extra={
         "config": "BASELINE configs[2] shape: 2,000,000 Gaussians, 64x2650 Waymo-style grid", "rays": [H, W], "gaussians": 2_000_000,
         "C_mean": float(f32[0]["n_cand"].mean()), "K_mean": float(f32[0]["n_comp"].mean()), "K_max": int(f32[0]["n_comp"].max())})
 
@@ -74,9 +76,11 @@ def test_waymo_dynamic_4m_matches_oracle_within_the_floor():
     f32 = oracle_pair(sc, o, d, 3, scenes.BG_DEFAULT, dL, "f32")
     f64 = oracle_pair(sc, o, d, 3, scenes.BG_DEFAULT, dL, "f64")
     h = run_hip(sc, o, d, 3, scenes.BG_DEFAULT, dL)
-    # fp64-arbitrated gate: the fraction statistic holds at the claim's 1.1; the relative L2 of ONE channel (final transmittance: a single
-    # restart-epsilon ray carries it) is 2.5 x the fp32 oracle's -- measured, stated in BASELINE.md section 6, gated at 3.5 here
-    parity_report("waymo_dynamic_4m", h, f32, f64, f64_k=(1.1, 3.5), extra={
+    # fp64-arbitrated gate: asserted at the claim's own (1.1, 1.25) with the threshold events named, counted, certified and masked (tests/event_gate.py;
+    # round 5 gated the L2 of this scene at a factor of 3.5 read off its own measurement); the unmasked table keeps the floor-relative bounds
+    from tests.event_gate import event_masked_gate
+    event_masked_gate("waymo_dynamic_4m", sc, o, d, 3, scenes.BG_DEFAULT, dL, f32[0], f64[0])
+    parity_report("waymo_dynamic_4m", h, f32, f64, f64_k=None, extra={
         "config": "BASELINE configs[4] shape on one GPU: 4,000,000 Gaussians, 64x2650 Waymo-style grid", "rays": [H, W], "gaussians": P,
         "C_mean": float(f32[0]["n_cand"].mean()), "K_mean": float(f32[0]["n_comp"].mean()), "K_max": int(f32[0]["n_comp"].max())})
 
