@@ -209,6 +209,7 @@ struct lrt_state {
     LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int deferred_accum; float* acc_ptr; long long acc_serial; int acc_pending;   // option deferred_accum: a training forward leaves `accum` all-zero, the backward of that forward writes the per-Gaussian sums of composite weights (forward.cu:268) into it
+    int zero_in_prep;    // 1 (default): the bucketed backward clears the gradient tensors inside k_bwd_prep2 (streaming) instead of rows of zeros from k_bk_sort
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int timing_every; unsigned timer_calls[4];      // see ScopedTimer
     int colour_variant;  // 1 (default): four lanes per hit in k_fwd_colour when the SH table is (16, 3); 0: lane per hit (any table shape)
@@ -271,6 +272,7 @@ struct TraceParams {
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int hit_cap; int hw;
     float2* hit_wa;        // deferred-colour forward: per recorded hit (composite weight, unclamped op*G)
     int prezeroed;         // backward: the gradient tensors are all-zero on entry (option grads_prezeroed): no zero rows are stored
+    int zero_in_prep;      // backward: k_bwd_prep2 clears the gradient tensors whole (round 6), k_bk_sort stores no rows of zeros
     int fast_prep;         // backward: hit_wa / hit_pk hold the forward's alpha and colour of every recorded hit
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
@@ -808,7 +810,7 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
-    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20;
+    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 1;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
@@ -911,6 +913,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
+    if (!strcmp(name, "zero_in_prep")) { st->zero_in_prep = value ? 1 : 0; return LRT_OK; }   // A/B switch of the bucketed backward's zero fill (see k_bwd_prep2)
     if (!strcmp(name, "carry_order")) { st->carry = value ? 1 : 0; st->carry_stale = 1; return LRT_OK; }   // 1 (default): builds of an unchanged number of primitives keep the last full sort's order (k_pack + k_make_tree, or the cull index for ray-culled builds); 0: every build sorts (the reference rebuilds its GAS from scratch)
     if (!strcmp(name, "carry_max_age")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_age must be >= 0"); st->carry_max_age = value; return LRT_OK; }   // builds between two full sorts at most (32)
     if (!strcmp(name, "carry_max_inv")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_inv must be >= 0"); st->carry_max_inv = value; return LRT_OK; }   // per mille of neighbour pairs out of Morton order (leaf-sized cells) that makes the next build sort again (20)
@@ -1128,6 +1131,7 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
         case 5: src = st->hit_n; bytes = (long long)st->hit_rays_cap * 4; break;                          // composited hits per ray of the last recording forward
         case 6: src = st->hit_t; bytes = (long long)st->hit_rays_cap * st->hit_cap_alloc * 4; break;      // their depths, [ray][hit_cap]
         case 7: src = st->hit_g; bytes = (long long)st->hit_rays_cap * st->hit_cap_alloc * 4; break;      // their Gaussians
+        case 8: src = st->hit_wa; bytes = (long long)st->hit_rays_cap * st->hit_cap_alloc * 8; break;     // their (composite weight, un-clamped opacity x G) (deferred-colour forward)
         default: LRT_FAIL(LRT_ERR_ARG, "lrt_debug_read: unknown buffer %d", which);
     }
     long long n = bytes < max_bytes ? bytes : max_bytes;
@@ -1768,6 +1772,7 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
                 const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
                 tp.fast_prep = st->fast_valid;
+                tp.zero_in_prep = (tp.fast_prep && !st->grads_prezeroed && st->zero_in_prep) ? 1 : 0;
                 if (lds_nb > 48 * 1024) {
                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                     if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));

@@ -12,9 +12,10 @@ measurement.  This module replaces the factor by an argument:
   2. the HIP path may not have more event rays than the reference's own fp32 arithmetic (the fp32 oracle) + 3 sigma of counting noise;
   3. every HIP event ray must be CERTIFIED as a knife edge by the brute-force float64 restatement (oracle/bruteforce.py: every quad
      intersected analytically, no tree, shares no code with the C oracle): at the depth where the sequences part there must be a candidate
-     within 2e-6 (relative) of a restart point, or two candidates closer than 1e-6 (relative), or an alpha within 1e-4 (relative) of 1/255, or
-     a transmittance within 1e-4 (relative) of the stop, or a hit within 1e-6 of the 0.2 m threshold.  A sequence that parts from the fp64
-     oracle's anywhere else is a BUG and fails the test;
+     within 2e-6 (relative) of a restart point, or two candidates closer than 1e-6 (relative), or an alpha within 5e-4 (relative) of 1/255, or
+     a quad met within 2e-4 (relative) of its rim, or a hit within 1e-6 of the 0.2 m threshold; a 1e-4 transmittance stop one hit apart is
+     certified from the HIP path's OWN recorded alphas (its transmittance differs from the exact one by x, every alpha within 2e-3, and the exact
+     stop test lies within 2 x + 1e-5 of the threshold).  A sequence that parts from the fp64 oracle's anywhere else is a BUG and fails the test;
   4. with the event rays of BOTH fp32 implementations masked (upstream gradient zero, image rows taken from the fp64 oracle) every channel and
      every gradient must satisfy the claim itself -- HIP no farther from the fp64 oracle than 1.1 x (fraction beyond tolerance) / 1.25 x
      (relative L2) the fp32 oracle is -- with no scene-specific factor and no "2 x tolerance" escape.
@@ -32,7 +33,11 @@ from oracle.bruteforce import QuadScene
 from tests.hip_util import DEV, DEFAULT_OPTS, GRAD_TOL, OUT_TOL, OUT_CHANNELS, parity_stats, settings
 
 TRACE_CAP = 192
-EDGE = {"restart": 2e-6, "order": 1e-6, "alpha": 1e-4, "tstop": 1e-4, "near": 1e-6}       # relative closeness that makes a knife edge
+# relative closeness that makes a knife edge.  restart / order / near are statements about t (fp32: 0.5-4 ulp = 6e-8 .. 5e-7); alpha = op exp(-(u^2+v^2)/2)
+# carries the cancellation of (u, v) = L (o + t d - mu) through the exponent (|u|, |v| up to 3.3: 1e-4 .. 5e-4 relative at the quad's rim), the
+# transmittance the product of up to a hundred (1 - alpha) factors -- the stop test one hit apart is certified from the implementation's own recorded
+# alphas instead of a fixed margin (certify) --; "rim": the ray meets the quad within that (u, v) error of its edge
+EDGE = {"restart": 2e-6, "order": 1e-6, "alpha": 5e-4, "tstop": 1e-4, "near": 1e-6, "rim": 2e-4}
 
 
 def trace_sequences(tr, HW, cap=TRACE_CAP):
@@ -51,7 +56,10 @@ def hip_sequences(state, HW):
     for which, arr in ((5, hn), (7, hg)):
         got = state._lib.lrt_debug_read(h, which, arr.ctypes.data_as(C.c_void_p), C.c_longlong(arr.nbytes), None)
         assert got >= arr.nbytes, (which, got, arr.nbytes)
-    return [hg[r, :hn[r]] for r in range(HW)], hn >= cap
+    wa = np.empty((HW, cap, 2), np.float32)                           # (composite weight, un-clamped opacity x G) per recorded hit
+    got = state._lib.lrt_debug_read(h, 8, wa.ctypes.data_as(C.c_void_p), C.c_longlong(wa.nbytes), None)
+    assert got >= wa.nbytes, (8, got, wa.nbytes)
+    return [hg[r, :hn[r]] for r in range(HW)], hn >= cap, wa
 
 
 def knife_edges(g, t, al):
@@ -82,8 +90,11 @@ def knife_edges(g, t, al):
             if abs(q / 1e-4 - 1.0) < EDGE["tstop"]:
                 edges.append((float(t[k]), "tstop", float(abs(q / 1e-4 - 1.0))))
             if q < 1e-4:
+                edges.append((float(t[k]), "stop", float(abs(q / 1e-4 - 1.0))))      # where the exact loop stops, and by how much
                 stop = True
                 break
+            if q < 1.05e-4:
+                edges.append((float(t[k]), "stop", float(abs(q / 1e-4 - 1.0))))      # ... or nearly does
             T = q
         if stop or len(chunk) < 16:
             break
@@ -95,10 +106,24 @@ def knife_edges(g, t, al):
     return edges
 
 
-def certify(qs, o_r, d_r, seq_x, seq64, subset=None, sc=None):
+def quad_uv(sc, qs, g, o_r, d_r):
+    """(u, v, half extent, t) of the ray on Gaussian g's quad plane in float64, from the full-scene QuadScene."""
+    if qs is None or qs.flim[g] < 0:
+        return None
+    o = np.asarray(o_r, np.float64); d = np.asarray(d_r, np.float64)
+    den = float(qs.n[g] @ d)
+    if den == 0.0:
+        return None
+    t = float(((qs.mu[g] - o) * qs.n[g]).sum() / den)
+    p = o + t * d - qs.mu[g]
+    return float(qs.U[g] @ p), float(qs.V[g] @ p), float(qs.flim[g]), t
+
+
+def certify(qs, o_r, d_r, seq_x, seq64, subset=None, sc=None, alpha_x=None, rim_cands=None):
     """Is the place where `seq_x` parts from the fp64 sequence a knife edge?  -> (kind or None, margin, depth of the divergence).
     subset: evaluate the brute-force intersection on these Gaussians only (every candidate any implementation looked at on this ray) instead of
     on all P -- the large scenes' hundreds of event rays x millions of quads; the first rays of every scene take the full scene and must agree."""
+    certify.last_diag = None
     if subset is not None:
         idx = np.unique(np.asarray(subset, np.int64))
         q2 = QuadScene(sc["means"][idx], sc["scales"][idx], sc["rotations"][idx], sc["opacities"][idx])
@@ -111,16 +136,45 @@ def certify(qs, o_r, d_r, seq_x, seq64, subset=None, sc=None):
     i = next((k for k in range(m) if int(seq_x[k]) != int(seq64[k])), m)
     involved = [int(s[i]) for s in (seq_x, seq64) if i < len(s)]
     depths = [where[q] for q in involved if q in where]
-    if not depths:
-        return None, None, None
-    t_div = min(depths)
+    # the depth window in which the two loops part: from the last hit both composited to the first one they disagree about.  The deciding
+    # candidate need not be composited by either side (the hit at which ONE loop stops; a candidate one loop never sees), so every candidate and
+    # every looked-at quad in the window is examined
+    t_prev = where.get(int(seq64[i - 1]), 0.0) if i > 0 else 0.0
+    t_div = min(depths) if depths else None
+    hi = (t_div if t_div is not None else (float(t[-1]) if len(t) else t_prev)) * (1.0 + 2e-6) + 3e-5
+    lo = t_prev - 3e-5
+    # the implementation's own transmittance error at the divergence, from the alphas it recorded (a stop one hit apart is a knife edge exactly
+    # when the exact stop test lies within that error of the threshold)
+    own = None
+    if alpha_x is not None and len(alpha_x) >= i and i > 0:
+        a64 = {int(gg): float(aa) for gg, aa in zip(g.tolist(), al.tolist())}
+        if all(int(q) in a64 for q in seq64[:i]):
+            ax = np.minimum(0.99, np.asarray(alpha_x[:i], np.float64)); a6 = np.array([a64[int(q)] for q in seq64[:i]])
+            if float(np.max(np.abs(ax / a6 - 1.0))) < 2e-3:               # every alpha arithmetic-close to the exact one
+                own = abs(float(np.prod(1.0 - ax)) / float(np.prod(1.0 - a6)) - 1.0)
     best = None
     for (tl, kind, marg) in knife_edges(g, t, al):
-        # the knife edge sits AT the divergence: the candidate on the restart window / the pair that swaps / the hit on a threshold is one of the
-        # hits the sequences disagree about (its depth within the restart epsilon's own width of the divergence)
-        if abs(tl - t_div) <= 3e-5 + 2e-6 * t_div:
-            if best is None or marg < best[1]:
-                best = (kind, marg)
+        if not (lo <= tl <= hi):
+            continue
+        if kind == "stop":
+            if not (marg <= 2.0 * (own if own is not None else 5e-5) + 1e-5):
+                continue
+            kind = "tstop"
+        if best is None or marg < best[1]:
+            best = (kind, marg)
+    if best is None and qs is not None:
+        # a quad met at its RIM: a candidate for one arithmetic, a miss for the other (it may be absent from the float64 candidate list altogether)
+        looked = subset if subset is not None else rim_cands
+        cand = set(involved) | (set(int(x) for x in np.asarray(looked).tolist()) if looked is not None else set())
+        for q in cand:
+            uvf = quad_uv(sc, qs, q, o_r, d_r)
+            if uvf is None:
+                continue
+            u, v, fl, tq = uvf
+            m_ = abs(max(abs(u), abs(v)) - fl) / fl
+            if m_ < EDGE["rim"] and lo <= tq <= hi and (best is None or m_ < best[1]):
+                best = ("rim", float(m_))
+    certify.last_diag = {"window": [lo, hi], "own_T_error": own}
     return (best[0], best[1], t_div) if best else (None, None, t_div)
 
 
@@ -152,7 +206,7 @@ def event_masked_gate(name, sc, o, d, deg, bg, dL, f32_fw, f64_fw, opts=None, ma
     out, acc = tr(ro, rd, None, t["means"], torch.zeros_like(t["means"]), shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
                   rotations=t["rotations"], tracer_settings=settings(bg, deg))
     torch.cuda.synchronize()
-    shp, trh = hip_sequences(tr.optix_context, HW)
+    shp, trh, hip_wa = hip_sequences(tr.optix_context, HW)
     same = lambda a, b: len(a) == len(b) and np.array_equal(np.asarray(a, np.int64), np.asarray(b, np.int64))
     usable = ~(tr64 | tr32 | trh)                                      # (a truncated trace says nothing: such rays are masked, and counted)
     ev_hip = np.array([usable[r] and not same(shp[r], s64[r]) for r in range(HW)])
@@ -169,12 +223,14 @@ def event_masked_gate(name, sc, o, d, deg, bg, dL, f32_fw, f64_fw, opts=None, ma
     n32 = traces["f32"]["n"].reshape(HW); n64 = traces["f64"]["n"].reshape(HW)
     for nr, r in enumerate(rays[:max_certify]):
         looked_at = np.concatenate([g32[r, :n32[r]], g64[r, :n64[r]], np.asarray(shp[r], np.int32)])
-        kind, marg, t_div = certify(qs, o2[r], d2[r], shp[r], s64[r], subset=looked_at, sc=sc)
+        kind, marg, t_div = certify(qs, o2[r], d2[r], shp[r], s64[r], subset=looked_at, sc=sc, alpha_x=hip_wa[r, :len(shp[r]), 1])
         if nr < 12:                                                   # the whole scene, every quad: the same verdict
-            k_full, m_full, _ = certify(qs, o2[r], d2[r], shp[r], s64[r])
-            assert k_full == kind, (name, int(r), kind, k_full)
+            k_full, m_full, _ = certify(qs, o2[r], d2[r], shp[r], s64[r], alpha_x=hip_wa[r, :len(shp[r]), 1], rim_cands=looked_at)
+            assert (k_full is None) == (kind is None), (name, int(r), kind, k_full)
         if kind is None:
-            uncertified.append({"ray": int(r), "depth": t_div, "hip": [int(x) for x in shp[r][:40]], "f64": [int(x) for x in s64[r][:40]]})
+            m_ = min(len(shp[r]), len(s64[r])); i_ = next((k for k in range(m_) if int(shp[r][k]) != int(s64[r][k])), m_)
+            uncertified.append({"ray": int(r), "depth": t_div, "first_difference": int(i_), "len": [len(shp[r]), len(s64[r])], "diag": getattr(certify, "last_diag", None),
+                                "hip": [int(x) for x in shp[r][max(i_ - 2, 0):i_ + 4]], "f64": [int(x) for x in s64[r][max(i_ - 2, 0):i_ + 4]]})
         else:
             kinds[kind] = kinds.get(kind, 0) + 1
     if count_only:                                                    # (a comparison run: events counted and certified, nothing masked or asserted)

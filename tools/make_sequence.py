@@ -85,7 +85,7 @@ def make(shape: str, out: str, n_frames: int, scale: float = 1.0, device="cuda:0
                 tb.frame[f] = (torch.as_tensor(boxes["translation"][a, k], device=dev), torch.as_tensor(boxes["quaternion"][a, k], device=dev).reshape(1, 4), None, None)
             tbs.append(tb)
     assets = [_GT(bg, dev)] + [_GT(a_, dev, tb) for a_, tb in zip(actors, tbs)]
-    args = types.SimpleNamespace(dynamic=boxes is not None, opt=types.SimpleNamespace(use_rayhit=False), pipe=types.SimpleNamespace())
+    args = types.SimpleNamespace(dynamic=boxes is not None, opt=types.SimpleNamespace(use_rayhit=True), pipe=types.SimpleNamespace())      # ray-drop = softmax([hit, drop]): a return where the accumulated weight exceeds the final transmittance
     from lidar_rt_amd.training import RangeFrames
     old = renderer.tracer_2dgs, renderer.use_fused_preprocess, renderer.deferred_accum
     renderer.tracer_2dgs, renderer.use_fused_preprocess, renderer.deferred_accum = None, False, False
