@@ -275,6 +275,10 @@ def event_masked_gate(name, sc, o, d, deg, bg, dL, f32_fw, f64_fw, opts=None, ma
     try:
         dd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity")
         os.makedirs(dd, exist_ok=True)
+        if os.environ.get("LRT_GATE_DUMP") == "1":                     # developer switch: the gradient tables themselves, for a look at who carries a statistic
+            np.savez_compressed(os.path.join(dd, name + "_grads.npz"), **{f"hip_{k}": hip["grads"][k] for k in hip["grads"]},
+                                **{f"f32_{k}": bw["f32"][k] for k in bw["f32"]}, **{f"f64_{k}": bw["f64"][k] for k in bw["f64"]},
+                                means=sc["means"], scales=sc["scales"], opacities=sc["opacities"], masked=rows)
         with open(os.path.join(dd, name + "_events.json"), "w") as f:
             json.dump(rec, f, indent=1)
     except OSError:

@@ -48,7 +48,7 @@ def region_of(k):
         return "forward"
     if k.startswith("k_bwd_") or k.startswith("k_bk_") or k.startswith("k_trace<true>"):
         return "backward"
-    if k.startswith(("k_morton", "k_rs_", "k_make_", "k_level", "k_upper", "k_tree", "k_pack", "k_cone", "rocprim::")):
+    if k.startswith(("k_morton", "k_rs_", "k_make_", "k_level", "k_upper", "k_tree", "k_pack", "k_cone", "k_drift", "k_index", "rocprim::")):
         return "build"
     return "other"
 
