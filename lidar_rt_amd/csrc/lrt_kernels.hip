@@ -218,7 +218,7 @@ struct lrt_state {
     int morton_extra;    // the build sorts log2(P) + morton_extra Morton bits (default 4: cells ~16x finer than the mean primitive spacing)
     int fused_tree, fused_hist;   // 1 (default): records + tree levels 1-3 in one launch (k_make_tree) + k_tree_top; digit histograms counted by k_morton
     int no_cull;         // debug: visit every non-empty child (no ray/box culling)
-    float* dbg; size_t dbg_floats;
+    float* dbg; size_t dbg_floats; int dbg_wgclk;
     // composited-hit record (forward with training=1 -> replay backward)
     float* hit_t; int* hit_g; int* hit_n; int* hit_ovf; int* hit_ovf_host; hipEvent_t hit_ev;
     unsigned* inv_words; // 64 words: neighbour pairs of the carried build order found out of Morton order (k_make_tree), summed and cleared by the forward's epilogue
@@ -233,7 +233,7 @@ struct lrt_state {
     // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
     int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream; int* near_list; size_t near_cap;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes; int lpt; int tile_cost_ready;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -265,7 +265,8 @@ struct TraceParams {
     const float* means; const float* scales; const float* rots; const float* opac; float mod;
     const float* out9_in; const float* dL_dout;
     float* d_means; float* d_shs; float* d_opac; float* d_scales; float* d_rots;
-    unsigned* tile_counter;
+    unsigned* tile_counter; int tq_stride;          // the eight tile queues' ticket counters, tq_stride words apart (k_fwd_cr4: 32, a 128-byte line each)
+    unsigned long long* wg_clk;                     // developer option dbg_wgclk: the forward's schedule -- [2 blocks] workgroup start / end, then [2 n_tiles] tile start / end (100 MHz clock)
     unsigned long long* stats;
     float* dbg;                                     // debug: per ray 64 floats = up to 32 consumed (t, gidx) pairs
     // composited-hit record written by the forward (training) and replayed by the backward: entry j of ray r at [r*hit_cap + j]
@@ -286,6 +287,8 @@ struct TraceParams {
     float slab0; int* err_flag; float* cr_lists;
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
     float* tile_w0;        // k_fwd_cr4: per tile, the first-slab width learnt in the previous frame (0 = none yet)
+    unsigned* tile_cost;   // k_fwd_cr4: per tile, its length in this launch (100 MHz clocks) -- the next forward of the same tiling balances its eight tile queues by them
+    const unsigned* tile_bounds; // ... [9] first tile column of queue 0..7 and tiles_x (written by k_fwd_init: tile_stripes); null = eight stripes of equal width
     // rays with a quad closer than LRT_T_NEAR: listed by the trace kernel, resolved by k_fwd_near (the reference's stale-slot rule)
     int* near_list; unsigned* near_count;
     unsigned* near_done; const float* naos;   // re-tracing backward: finished-workgroup counter (its last workgroup replays the near rays), AoS nodes for that replay
@@ -627,18 +630,77 @@ __global__ void __launch_bounds__(256) k_xchg_apply(int P, int B, int N, int ran
 // The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
 // tree_nodes != null: the LBVH of the build in front of this forward still lacks its levels >= 4 (k_make_tree only combined the level-3
 // boxes): the LAST workgroup of this launch writes them (tree_finish_top) -- every consumer of the tree runs behind this launch.
+// tile_bounds != null: ONE more workgroup (in front of the finishing one) cuts the tile columns into k_fwd_cr4's eight queues -- one per XCD, worked on
+// in row-major order, emptied queues steal from the next -- so that every queue holds an eighth of the tile LENGTHS of the previous forward of this
+// tiling, not an eighth of the tiles (measured on S1M: the queues of equal width held 40 .. 77 ms of tile time, ran dry between 260 and 347 us of a
+// 470 us launch, and the tiles stolen across XCDs at the end took twice as long as their neighbours had).
+__device__ void tile_stripes(int tiles_x, int tiles_y, const unsigned* __restrict__ cost, unsigned* __restrict__ bounds, unsigned* s_w)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned* const s_part = s_w;               // [4] wave totals
+    unsigned* const s_col = s_w + 8;            // [256] inclusive prefix of a chunk of 256 columns
+    unsigned* const s_tot = s_w + 8 + 256;      // [1] total
+    // pass 1: the total (lengths in units of 1.28 us: a column of 64 tiles of 10 ms stays below 2^20)
+    unsigned mine = 0u;
+    for (int i = tid; i < tiles_x * tiles_y; i += 256) mine += cost[i] >> 7;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) s_part[wv] = mine;
+    __syncthreads();
+    const unsigned total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (tid == 0) { bounds[0] = 0u; bounds[8] = (unsigned)tiles_x; }
+    if (total == 0u || tiles_x < 8) { if (tid >= 1 && tid < 8) bounds[tid] = (unsigned)((tid * tiles_x) >> 3); return; }
+    // pass 2: column sums, their running total; boundary k = the first column at which the running total reaches k / 8 of the whole
+    unsigned carry = 0u;
+    __shared__ unsigned s_b[9];
+    if (tid < 9) s_b[tid] = (tid == 8) ? (unsigned)tiles_x : 0u;
+    for (int c_lo = 0; c_lo < tiles_x; c_lo += 256) {
+        const int c = c_lo + tid;
+        unsigned v = 0u;
+        if (c < tiles_x) for (int y = 0; y < tiles_y; y++) v += cost[(size_t)y * tiles_x + c] >> 7;
+        unsigned incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        __syncthreads();
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        unsigned before = carry;
+        for (int k = 0; k < wv; k++) before += s_part[k];
+        incl += before;
+        const unsigned excl = incl - v;
+        if (c < tiles_x)
+            for (int k = 1; k < 8; k++) {
+                const unsigned long long want = ((unsigned long long)total * (unsigned)k + 7ull) >> 3;
+                if ((unsigned long long)excl < want && (unsigned long long)incl >= want) s_b[k] = (unsigned)(c + 1);      // the column that crosses k / 8 closes queue k - 1
+            }
+        carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+    __syncthreads();
+    if (tid == 0) {                                                  // every queue at least one column wide, boundaries increasing
+        unsigned prev = 0u;
+        for (int k = 1; k < 8; k++) {
+            unsigned bk = s_b[k];
+            if (bk < prev + 1u) bk = prev + 1u;
+            const unsigned hi = (unsigned)tiles_x - (unsigned)(8 - k);
+            if (bk > hi) bk = hi;
+            bounds[k] = bk; prev = bk;
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
                                                   unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag,
-                                                  float* tree_nodes, float* tree_naos, const TreeLayout lay, unsigned* tree_top)
+                                                  float* tree_nodes, float* tree_naos, const TreeLayout lay, unsigned* tree_top,
+                                                  const unsigned* tile_cost, unsigned* tile_bounds, int tiles_x, int tiles_y)
 {
     __shared__ float s_box[2 * 1536];
+    const int n_fin = (tree_nodes && gridDim.x > 1) ? 1 : 0, n_ord = tile_bounds ? 1 : 0;
     if (tree_nodes && blockIdx.x == gridDim.x - 1) { tree_finish_top(tree_nodes, tree_naos, lay, tree_top, (int)threadIdx.x, 256, s_box); if (gridDim.x > 1) return; }
-    const int nb_ = (tree_nodes && gridDim.x > 1) ? (int)gridDim.x - 1 : (int)gridDim.x;       // the finishing workgroup takes no share of the fills
+    const int nb_ = (int)gridDim.x - n_fin - n_ord;                 // the finishing and the ordering workgroups take no share of the fills (the launcher keeps nb_ >= 1)
+    if ((int)blockIdx.x >= nb_) { tile_stripes(tiles_x, tiles_y, tile_cost, tile_bounds, reinterpret_cast<unsigned*>(s_box)); return; }
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = nb_ * blockDim.x;
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
     // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
     // [24] near rays found by the re-tracing backward, [25] its finished workgroups
     if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;      // ([32..95]: the build's order-decay counters, summed and cleared by the epilogue)
+    if (i >= 32 && i < 40) ctrl[96 + 32 * (i - 32)] = 0u;         // k_fwd_cr4's eight ticket counters, a 128-byte line each: away from the words every tile adds to (hit_count)
     float4* a4 = reinterpret_cast<float4*>(accum);
     if ((reinterpret_cast<uintptr_t>(accum) & 15) == 0) {
         for (int k = i; k < P / 4; k += stride) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -810,11 +872,11 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
-    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 1;
+    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 1; st->lpt = 1;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
-    if (hipMalloc(&st->ctrl, (32 + 64) * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, (32 + 64) * sizeof(unsigned)) != hipSuccess ||
+    if (hipMalloc(&st->ctrl, (32 + 64 + 8 * 32) * sizeof(unsigned)) != hipSuccess || hipMemset(st->ctrl, 0, (32 + 64 + 8 * 32) * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&st->hit_ovf_host, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&st->status_dev, st->hit_ovf_host, 0) != hipSuccess ||
         hipEventCreateWithFlags(&st->hit_ev, hipEventDisableTiming) != hipSuccess) {
@@ -927,7 +989,8 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fuse_fin")) { st->fuse_fin = value ? 1 : 0; return LRT_OK; }   // 0: k_fwd_fin as a launch of its own behind k_fwd_colour
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); if (value != 1 && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_tree=%d (the level-by-level / two-launch build) exists in the cross-check library only (-DLRT_LEGACY)", value); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_hist=0 (a histogram launch of its own, k_rs_hist) exists in the cross-check library only (-DLRT_LEGACY)"); st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
-    if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; return LRT_OK; }   // per-tile first-slab width carried between frames
+    if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; return LRT_OK; }
+    if (!strcmp(name, "lpt")) { st->lpt = value ? 1 : 0; st->tile_cost_ready = 0; return LRT_OK; }      // 1 (default): k_fwd_cr4's eight tile queues hold equal shares of the tile lengths of the previous forward of the same tiling (needs learn_slab's per-tile table)   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
     if (!strcmp(name, "tile16_w")) {           // rays per tile row of the 16-ray tiles (collect & resolve forward)
@@ -945,6 +1008,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
         if ((value == 1 || value == 2) && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: bwd_mode %d (replay + atomics / sorted reduction) exists in the cross-check library only (-DLRT_LEGACY); the product has 3 (bucketed replay) and 0 (re-trace)", value);
         st->bwd_mode = value; st->replay_enabled = value > 0; st->hits_valid = 0; return LRT_OK;
     }
+    if (!strcmp(name, "dbg_wgclk")) { st->dbg_wgclk = value ? 1 : 0; return LRT_OK; }      // with debug_rays >= (blocks + tiles) / 16: k_fwd_cr4 (production instantiation) records its schedule into the debug buffer (lrt_debug_read 4)
     if (!strcmp(name, "debug_rays")) {        // value = max number of rays to record consumed hits for (0 = off)
         DeviceGuard dg(st->device);
         if (st->dbg) { (void)hipFree(st->dbg); st->dbg = nullptr; st->dbg_floats = 0; }
@@ -1455,13 +1519,23 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         rc = lrt_check_forward(st, 0);                                          // a finished earlier forward that overflowed is reported now
         if (rc) return rc;
     } else if (st->fwd_pending && hipEventQuery(st->hit_ev) == hipSuccess) (void)absorb_status(st);
+    bool lpt_sort = false; int lpt_tx = 0, lpt_ty = 0;
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         const bool fin_tree = st->tree_pending != 0;
-        lrt_launch(st->lrec, k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
+        // the tile queues of k_fwd_cr4 cut by work: when the last forward of this very tiling left its tile lengths behind
+        if (st->lpt && st->learn_slab && st->tile_cost_ready && st->tile_w0 && st->fwd_mode == 2 && P > 0) {
+            const int TW_ = 1 << st->tile16_w_log2, TH_ = C4_RAYS / TW_;
+            lpt_tx = (W + TW_ - 1) / TW_; lpt_ty = (H + TH_ - 1) / TH_;
+            const int key_[3] = {H * 65536 + W, st->tile16_w_log2, (int)(st->slab0 * 1000.f)};
+            lpt_sort = lpt_tx >= 8 && lpt_tx * lpt_ty <= st->tile_w0_n && memcmp(key_, st->tile_w0_key, sizeof(key_)) == 0;
+        }
+        unsigned* const tcost = lpt_sort ? reinterpret_cast<unsigned*>(st->tile_w0) + st->tile_w0_n : nullptr;
+        lrt_launch(st->lrec, k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0) + (lpt_sort ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
                            (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr),
-                           fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top);
+                           fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top,
+                           (const unsigned*)tcost, lpt_sort ? tcost + st->tile_w0_n : (unsigned*)nullptr, lpt_tx, lpt_ty);
         st->tree_pending = 0;
     }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
@@ -1529,7 +1603,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         const int TW = 1 << st->tile16_w_log2, TH = tile_rays / TW;
         tp.tw_log2 = st->tile16_w_log2;
         tp.tiles_x = (W + TW - 1) / TW; tp.tiles_y = (H + TH - 1) / TH; tp.n_tiles = tp.tiles_x * tp.tiles_y;
-        tp.tile_counter = st->tile_counter; tp.stats = st->stats_enabled ? st->stats : nullptr;
+        tp.tile_counter = st->ctrl + 96; tp.tq_stride = 32; tp.stats = st->stats_enabled ? st->stats : nullptr;
         tp.nsh = (deg + 1) * (deg + 1); tp.slab0 = st->slab0; tp.err_flag = st->err_flag; tp.c4_qlimit = (unsigned)st->c4_qlimit;
         tp.pack = (st->pack_valid && st->refine_ties) ? st->pack : nullptr;
         {   // start level of the walk: the highest level with at most `root_nodes` nodes (option; 1 = the root itself)
@@ -1539,7 +1613,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             while (l_ > 1 && cnt_[l_ - 1] <= st->root_nodes) l_--;
             tp.root_first = (unsigned)off_[l_]; tp.root_count = (unsigned)cnt_[l_];
         }
-        tp.dbg = (st->dbg && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
+        tp.dbg = (st->dbg && !st->dbg_wgclk && st->dbg_floats >= (size_t)tp.n_tiles * 8) ? st->dbg : nullptr;
         if (tp.n_tiles > 0) {
             // persistent workgroups: single waves, 4 per SIMD (k_fwd_cr) / 4-wave groups, st->wg4_per_cu per CU (k_fwd_cr4)
             // k_fwd_cr4: 8 waves per tile when every workgroup would get at most one tile anyway (few tiles: the launch lasts as
@@ -1571,20 +1645,27 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 st->cr_blocks_cap = cap;
             }
             tp.cr_lists = st->cr_lists;
+            tp.wg_clk = (st->dbg_wgclk && st->dbg && st->dbg_floats >= 4 * ((size_t)blocks + (size_t)tp.n_tiles)) ? (unsigned long long*)st->dbg : nullptr;
             tp.tile_w0 = nullptr;
             if (wg4 && st->learn_slab) {                             // widths are kept while the image size, tiling and default width stay the same
                 const int key[3] = {H * 65536 + W, tp.tw_log2, (int)(st->slab0 * 1000.f)};
                 if (tp.n_tiles > st->tile_w0_n) {
                     HIPCHK(hipStreamSynchronize(stream));
                     (void)hipFree(st->tile_w0); st->tile_w0 = nullptr; st->tile_w0_n = 0;
-                    HIPCHK(hipMalloc(&st->tile_w0, (size_t)tp.n_tiles * sizeof(float)));
+                    HIPCHK(hipMalloc(&st->tile_w0, (2 * (size_t)tp.n_tiles + 16) * sizeof(float)));      // [widths | lengths of the last launch | the queue boundaries made from them]
                     st->tile_w0_n = tp.n_tiles; st->tile_w0_key[0] = -1;
                 }
                 if (memcmp(key, st->tile_w0_key, sizeof(key)) != 0) {
-                    HIPCHK(lrt_memset_async(st->lrec, st->tile_w0, 0, (size_t)tp.n_tiles * sizeof(float), stream));
+                    HIPCHK(lrt_memset_async(st->lrec, st->tile_w0, 0, (2 * (size_t)st->tile_w0_n + 16) * sizeof(float), stream));
                     memcpy(st->tile_w0_key, key, sizeof(key));
+                    st->tile_cost_ready = 0;
                 }
                 tp.tile_w0 = st->tile_w0;
+                if (st->lpt && tp.tiles_x >= 8) {
+                    tp.tile_cost = reinterpret_cast<unsigned*>(st->tile_w0) + st->tile_w0_n;
+                    if (lpt_sort && lpt_tx == tp.tiles_x && lpt_ty == tp.tiles_y) tp.tile_bounds = tp.tile_cost + st->tile_w0_n;
+                    st->tile_cost_ready = 1;                        // (this launch writes every tile's length)
+                }
             }
             if (getenv("LRT_DEBUG_OCC")) {
                 int n0 = -1, n1 = -1, n2 = -1;
