@@ -648,7 +648,11 @@ __device__ void tile_stripes(int tiles_x, int tiles_y, const unsigned* __restric
     __syncthreads();
     const unsigned total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     if (tid == 0) { bounds[0] = 0u; bounds[8] = (unsigned)tiles_x; }
-    if (total == 0u || tiles_x < 8) { if (tid >= 1 && tid < 8) bounds[tid] = (unsigned)((tid * tiles_x) >> 3); return; }
+    if (total == 0u || tiles_x < 8) {
+        if (tid >= 1 && tid < 8) bounds[tid] = (unsigned)((tid * tiles_x) >> 3);
+        if (tiles_y <= 64) for (int idx = tid; idx < 8 * tiles_y; idx += 256) bounds[16 + 64 * (idx / tiles_y) + idx % tiles_y] = (unsigned)(idx % tiles_y);
+        return;
+    }
     // pass 2: column sums, their running total; boundary k = the first column at which the running total reaches k / 8 of the whole
     unsigned carry = 0u;
     __shared__ unsigned s_b[9];
@@ -681,8 +685,27 @@ __device__ void tile_stripes(int tiles_x, int tiles_y, const unsigned* __restric
             if (bk < prev + 1u) bk = prev + 1u;
             const unsigned hi = (unsigned)tiles_x - (unsigned)(8 - k);
             if (bk > hi) bk = hi;
-            bounds[k] = bk; prev = bk;
+            bounds[k] = bk; s_b[k] = bk; prev = bk;
         }
+    }
+    // the ROWS of every queue, longest first (bounds[16 + 64 q + rank] = tile row): a queue is worked on row by row (neighbouring tiles share nodes and
+    // records in the caches), and a launch that reaches its long rows last drains them on a few workgroups while the others have ended
+    if (tiles_y > 64) return;
+    __syncthreads();
+    unsigned* const s_rc = s_w + 512;           // [8][tiles_y] row lengths
+    for (int idx = tid; idx < 8 * tiles_y; idx += 256) {
+        const int q = idx / tiles_y, y = idx - q * tiles_y;
+        unsigned v = 0u;
+        for (unsigned c = s_b[q]; c < s_b[q + 1]; c++) v += cost[(size_t)y * tiles_x + c] >> 7;
+        s_rc[idx] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 8 * tiles_y; idx += 256) {
+        const int q = idx / tiles_y, y = idx - q * tiles_y;
+        const unsigned mine = s_rc[idx];
+        int rank = 0;
+        for (int y2 = 0; y2 < tiles_y; y2++) { const unsigned o = s_rc[q * tiles_y + y2]; rank += (o > mine || (o == mine && y2 < y)) ? 1 : 0; }
+        bounds[16 + 64 * q + rank] = (unsigned)y;
     }
 }
 __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
@@ -1626,7 +1649,11 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             // Round 5: 16 waves per tile (one workgroup per CU, 4096-entry rings) for launches of up to 1536 tiles -- a rank of an 8-way split: S1M 1024 tiles,
             // forward 0.153 / 0.140 -> 0.147 / 0.137 ms (ranks 0 / 4), the Waymo-4M shape 1344 tiles, 0.480 / 0.330 -> 0.422 / 0.300 ms; on the full S1M frame
             // (8192 tiles) 16 waves lose badly (0.94 against 0.63 ms): a tile's rounds do not get shorter in proportion, the barrier spans 1024 threads
-            int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : (tp.n_tiles <= 256 * 6 ? 16 : (tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
+            // Round 6 (behind the ticket fix of k_fwd_cr4, which had cost the small launches most): S1M 1024 tiles (420 hits per tile) 4 / 8 / 16 waves: forward
+            // 0.163 / 0.130 / 0.143 ms (rank 0), 0.136 / 0.125 / 0.140 (rank 4); the Waymo-4M shape, 1344 tiles of 800 hits: 8 / 16 waves 0.384 / 0.362 and 0.323 / 0.312.
+            // So 16 waves only for few AND dense tiles (>= 640 composited hits per tile in the last completed frame of this size).
+            const bool dense_tiles = st->est_valid && st->est_hw == HW && (size_t)st->est_hits >= (size_t)640 * (size_t)tp.n_tiles;
+            int nw = !wg4 ? 1 : (st->c4_waves ? st->c4_waves : ((tp.n_tiles <= 256 * 6 && dense_tiles) ? 16 : (tp.n_tiles <= 256 * 12 || heavy_tiles) ? 8 : 4));
             if (nw == 16 && (!(defer && record) || tp.stats != nullptr || tp.dbg != nullptr || st->c4_qlimit < C4_NQ)) nw = 8;      // 16 waves: the production variant only (and not with a lowered queue limit, a test option sized for the 1024-entry rings)
             // resident workgroups only: a workgroup that has to wait for a slot costs more than it brings (measured: 5 launched on 4 slots, forward +3 %).
             // 8-wave groups: half as many; the non-deferred and the statistics instantiations are compiled for 2 (4-wave) / 1 (8-wave) per CU
@@ -1652,11 +1679,11 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 if (tp.n_tiles > st->tile_w0_n) {
                     HIPCHK(hipStreamSynchronize(stream));
                     (void)hipFree(st->tile_w0); st->tile_w0 = nullptr; st->tile_w0_n = 0;
-                    HIPCHK(hipMalloc(&st->tile_w0, (2 * (size_t)tp.n_tiles + 16) * sizeof(float)));      // [widths | lengths of the last launch | the queue boundaries made from them]
+                    HIPCHK(hipMalloc(&st->tile_w0, (2 * (size_t)tp.n_tiles + 16 + 512) * sizeof(float)));      // [widths | lengths of the last launch | the queue boundaries and row orders made from them]
                     st->tile_w0_n = tp.n_tiles; st->tile_w0_key[0] = -1;
                 }
                 if (memcmp(key, st->tile_w0_key, sizeof(key)) != 0) {
-                    HIPCHK(lrt_memset_async(st->lrec, st->tile_w0, 0, (2 * (size_t)st->tile_w0_n + 16) * sizeof(float), stream));
+                    HIPCHK(lrt_memset_async(st->lrec, st->tile_w0, 0, (2 * (size_t)st->tile_w0_n + 16 + 512) * sizeof(float), stream));
                     memcpy(st->tile_w0_key, key, sizeof(key));
                     st->tile_cost_ready = 0;
                 }

@@ -43,8 +43,8 @@ for cand in (256, 512, 768, 1024, 1280, 1536, 2560):
         s = buf[:cand].astype(np.int64) - int(c0); e = buf[cand:2 * cand].astype(np.int64) - int(c0)
         if np.all(np.abs(s) < 10**7) and np.all(e > s) and np.all(e < 10**7): nb = cand
 nb = int(os.environ.get("BLOCKS", nb))
-ws, we = buf[:nb].astype(np.int64), buf[nb:2 * nb].astype(np.int64)
-tt = buf[2 * nb:2 * nb + 2 * n_tiles].astype(np.int64).reshape(n_tiles, 2)
+ws, we = (buf[:nb] & np.uint64(0xffffffffffff)).astype(np.int64), (buf[nb:2 * nb] & np.uint64(0xffffffffffff)).astype(np.int64)
+tt = (buf[2 * nb:2 * nb + 2 * n_tiles] & np.uint64(0xffffffffffff)).astype(np.int64).reshape(n_tiles, 2)      # (the end word carries the workgroup in its top 16 bits)
 t0 = ws.min()
 ws, we, tt = (ws - t0) / 100.0, (we - t0) / 100.0, (tt - t0) / 100.0      # us
 L = we.max()
