@@ -288,7 +288,8 @@ struct TraceParams {
     float4* ovf_list; unsigned* ovf_count; unsigned ovf_cap;
     float* tile_w0;        // k_fwd_cr4: per tile, the first-slab width learnt in the previous frame (0 = none yet)
     unsigned* tile_cost;   // k_fwd_cr4: per tile, its length in this launch (100 MHz clocks) -- the next forward of the same tiling balances its eight tile queues by them
-    const unsigned* tile_bounds; // ... [9] first tile column of queue 0..7 and tiles_x (written by k_fwd_init: tile_stripes); null = eight stripes of equal width
+    const unsigned* tile_bounds; // ... [9] first tile column of queue 0..7 and tiles_x, [16 + 64 q + k] the k-th tile row of queue q (tile_stripes); null = eight stripes of equal width, rows in order
+    unsigned* tile_bounds_next;  // where THIS forward's epilogue writes them for the next one
     // rays with a quad closer than LRT_T_NEAR: listed by the trace kernel, resolved by k_fwd_near (the reference's stale-slot rule)
     int* near_list; unsigned* near_count;
     unsigned* near_done; const float* naos;   // re-tracing backward: finished-workgroup counter (its last workgroup replays the near rays), AoS nodes for that replay
@@ -630,94 +631,13 @@ __global__ void __launch_bounds__(256) k_xchg_apply(int P, int B, int N, int ran
 // The forward's prologue in one launch: accum = 0 (P floats), out_i32 = -1 (trace_surfels.cpp:208), control words = 0.
 // tree_nodes != null: the LBVH of the build in front of this forward still lacks its levels >= 4 (k_make_tree only combined the level-3
 // boxes): the LAST workgroup of this launch writes them (tree_finish_top) -- every consumer of the tree runs behind this launch.
-// tile_bounds != null: ONE more workgroup (in front of the finishing one) cuts the tile columns into k_fwd_cr4's eight queues -- one per XCD, worked on
-// in row-major order, emptied queues steal from the next -- so that every queue holds an eighth of the tile LENGTHS of the previous forward of this
-// tiling, not an eighth of the tiles (measured on S1M: the queues of equal width held 40 .. 77 ms of tile time, ran dry between 260 and 347 us of a
-// 470 us launch, and the tiles stolen across XCDs at the end took twice as long as their neighbours had).
-__device__ void tile_stripes(int tiles_x, int tiles_y, const unsigned* __restrict__ cost, unsigned* __restrict__ bounds, unsigned* s_w)
-{
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned* const s_part = s_w;               // [4] wave totals
-    unsigned* const s_col = s_w + 8;            // [256] inclusive prefix of a chunk of 256 columns
-    unsigned* const s_tot = s_w + 8 + 256;      // [1] total
-    // pass 1: the total (lengths in units of 1.28 us: a column of 64 tiles of 10 ms stays below 2^20)
-    unsigned mine = 0u;
-    for (int i = tid; i < tiles_x * tiles_y; i += 256) mine += cost[i] >> 7;
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-    if (lane == 0) s_part[wv] = mine;
-    __syncthreads();
-    const unsigned total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    if (tid == 0) { bounds[0] = 0u; bounds[8] = (unsigned)tiles_x; }
-    if (total == 0u || tiles_x < 8) {
-        if (tid >= 1 && tid < 8) bounds[tid] = (unsigned)((tid * tiles_x) >> 3);
-        if (tiles_y <= 64) for (int idx = tid; idx < 8 * tiles_y; idx += 256) bounds[16 + 64 * (idx / tiles_y) + idx % tiles_y] = (unsigned)(idx % tiles_y);
-        return;
-    }
-    // pass 2: column sums, their running total; boundary k = the first column at which the running total reaches k / 8 of the whole
-    unsigned carry = 0u;
-    __shared__ unsigned s_b[9];
-    if (tid < 9) s_b[tid] = (tid == 8) ? (unsigned)tiles_x : 0u;
-    for (int c_lo = 0; c_lo < tiles_x; c_lo += 256) {
-        const int c = c_lo + tid;
-        unsigned v = 0u;
-        if (c < tiles_x) for (int y = 0; y < tiles_y; y++) v += cost[(size_t)y * tiles_x + c] >> 7;
-        unsigned incl = v;
-        for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-        __syncthreads();
-        if (lane == 63) s_part[wv] = incl;
-        __syncthreads();
-        unsigned before = carry;
-        for (int k = 0; k < wv; k++) before += s_part[k];
-        incl += before;
-        const unsigned excl = incl - v;
-        if (c < tiles_x)
-            for (int k = 1; k < 8; k++) {
-                const unsigned long long want = ((unsigned long long)total * (unsigned)k + 7ull) >> 3;
-                if ((unsigned long long)excl < want && (unsigned long long)incl >= want) s_b[k] = (unsigned)(c + 1);      // the column that crosses k / 8 closes queue k - 1
-            }
-        carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    }
-    __syncthreads();
-    if (tid == 0) {                                                  // every queue at least one column wide, boundaries increasing
-        unsigned prev = 0u;
-        for (int k = 1; k < 8; k++) {
-            unsigned bk = s_b[k];
-            if (bk < prev + 1u) bk = prev + 1u;
-            const unsigned hi = (unsigned)tiles_x - (unsigned)(8 - k);
-            if (bk > hi) bk = hi;
-            bounds[k] = bk; s_b[k] = bk; prev = bk;
-        }
-    }
-    // the ROWS of every queue, longest first (bounds[16 + 64 q + rank] = tile row): a queue is worked on row by row (neighbouring tiles share nodes and
-    // records in the caches), and a launch that reaches its long rows last drains them on a few workgroups while the others have ended
-    if (tiles_y > 64) return;
-    __syncthreads();
-    unsigned* const s_rc = s_w + 512;           // [8][tiles_y] row lengths
-    for (int idx = tid; idx < 8 * tiles_y; idx += 256) {
-        const int q = idx / tiles_y, y = idx - q * tiles_y;
-        unsigned v = 0u;
-        for (unsigned c = s_b[q]; c < s_b[q + 1]; c++) v += cost[(size_t)y * tiles_x + c] >> 7;
-        s_rc[idx] = v;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 8 * tiles_y; idx += 256) {
-        const int q = idx / tiles_y, y = idx - q * tiles_y;
-        const unsigned mine = s_rc[idx];
-        int rank = 0;
-        for (int y2 = 0; y2 < tiles_y; y2++) { const unsigned o = s_rc[q * tiles_y + y2]; rank += (o > mine || (o == mine && y2 < y)) ? 1 : 0; }
-        bounds[16 + 64 * q + rank] = (unsigned)y;
-    }
-}
 __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ accum, int n_i32, int32_t* __restrict__ out_i32,
                                                   unsigned* __restrict__ ctrl, const unsigned* __restrict__ build_flag,
-                                                  float* tree_nodes, float* tree_naos, const TreeLayout lay, unsigned* tree_top,
-                                                  const unsigned* tile_cost, unsigned* tile_bounds, int tiles_x, int tiles_y)
+                                                  float* tree_nodes, float* tree_naos, const TreeLayout lay, unsigned* tree_top)
 {
     __shared__ float s_box[2 * 1536];
-    const int n_fin = (tree_nodes && gridDim.x > 1) ? 1 : 0, n_ord = tile_bounds ? 1 : 0;
     if (tree_nodes && blockIdx.x == gridDim.x - 1) { tree_finish_top(tree_nodes, tree_naos, lay, tree_top, (int)threadIdx.x, 256, s_box); if (gridDim.x > 1) return; }
-    const int nb_ = (int)gridDim.x - n_fin - n_ord;                 // the finishing and the ordering workgroups take no share of the fills (the launcher keeps nb_ >= 1)
-    if ((int)blockIdx.x >= nb_) { tile_stripes(tiles_x, tiles_y, tile_cost, tile_bounds, reinterpret_cast<unsigned*>(s_box)); return; }
+    const int nb_ = (tree_nodes && gridDim.x > 1) ? (int)gridDim.x - 1 : (int)gridDim.x;       // the finishing workgroup takes no share of the fills
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = nb_ * blockDim.x;
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
     // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
@@ -1542,23 +1462,13 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         rc = lrt_check_forward(st, 0);                                          // a finished earlier forward that overflowed is reported now
         if (rc) return rc;
     } else if (st->fwd_pending && hipEventQuery(st->hit_ev) == hipSuccess) (void)absorb_status(st);
-    bool lpt_sort = false; int lpt_tx = 0, lpt_ty = 0;
     {   // accum = 0, out_i32 = -1, tile queues / overflow flags / counters = 0: one launch
         const size_t work = (size_t)(P / 4 + 4) > (size_t)H * W ? (size_t)(P / 4 + 4) : (size_t)H * W;
         int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         const bool fin_tree = st->tree_pending != 0;
-        // the tile queues of k_fwd_cr4 cut by work: when the last forward of this very tiling left its tile lengths behind
-        if (st->lpt && st->learn_slab && st->tile_cost_ready && st->tile_w0 && st->fwd_mode == 2 && P > 0) {
-            const int TW_ = 1 << st->tile16_w_log2, TH_ = C4_RAYS / TW_;
-            lpt_tx = (W + TW_ - 1) / TW_; lpt_ty = (H + TH_ - 1) / TH_;
-            const int key_[3] = {H * 65536 + W, st->tile16_w_log2, (int)(st->slab0 * 1000.f)};
-            lpt_sort = lpt_tx >= 8 && lpt_tx * lpt_ty <= st->tile_w0_n && memcmp(key_, st->tile_w0_key, sizeof(key_)) == 0;
-        }
-        unsigned* const tcost = lpt_sort ? reinterpret_cast<unsigned*>(st->tile_w0) + st->tile_w0_n : nullptr;
-        lrt_launch(st->lrec, k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0) + (lpt_sort ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
+        lrt_launch(st->lrec, k_fwd_init, dim3(blocks + (fin_tree ? 1 : 0)), dim3(256), 0, stream, P, accum, (int)((size_t)H * W), out_i32, st->ctrl,
                            (const unsigned*)(st->cone_flag_live ? st->cone + 11 : nullptr),
-                           fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top,
-                           (const unsigned*)tcost, lpt_sort ? tcost + st->tile_w0_n : (unsigned*)nullptr, lpt_tx, lpt_ty);
+                           fin_tree ? st->nodes : (float*)nullptr, st->nodes_aos, st->tree_lay, st->tree_top);
         st->tree_pending = 0;
     }
     TraceParams tp; memset(&tp, 0, sizeof(tp));
@@ -1674,6 +1584,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             tp.cr_lists = st->cr_lists;
             tp.wg_clk = (st->dbg_wgclk && st->dbg && st->dbg_floats >= 4 * ((size_t)blocks + (size_t)tp.n_tiles)) ? (unsigned long long*)st->dbg : nullptr;
             tp.tile_w0 = nullptr;
+            const bool dfr_ = defer && record && st->fuse_fin;
             if (wg4 && st->learn_slab) {                             // widths are kept while the image size, tiling and default width stay the same
                 const int key[3] = {H * 65536 + W, tp.tw_log2, (int)(st->slab0 * 1000.f)};
                 if (tp.n_tiles > st->tile_w0_n) {
@@ -1690,8 +1601,10 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
                 tp.tile_w0 = st->tile_w0;
                 if (st->lpt && tp.tiles_x >= 8) {
                     tp.tile_cost = reinterpret_cast<unsigned*>(st->tile_w0) + st->tile_w0_n;
-                    if (lpt_sort && lpt_tx == tp.tiles_x && lpt_ty == tp.tiles_y) tp.tile_bounds = tp.tile_cost + st->tile_w0_n;
-                    st->tile_cost_ready = 1;                        // (this launch writes every tile's length)
+                    // the queue boundaries and row orders this forward's epilogue (k_fwd_colour, first workgroup: tile_stripes) makes from the lengths: read by
+                    // the NEXT forward of this tiling
+                    if (st->tile_cost_ready) tp.tile_bounds = tp.tile_cost + st->tile_w0_n;
+                    if (dfr_) { tp.tile_bounds_next = tp.tile_cost + st->tile_w0_n; st->tile_cost_ready = 1; }
                 }
             }
             if (getenv("LRT_DEBUG_OCC")) {
