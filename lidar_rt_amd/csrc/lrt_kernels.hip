@@ -233,7 +233,7 @@ struct lrt_state {
     // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
     int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream; int* near_list; size_t near_cap;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes; int lpt; int tile_cost_ready;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes; int lpt; int tile_cost_ready; int bk_columns;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -302,7 +302,7 @@ struct TraceParams {
     unsigned* bk_aux;                      // [BK_RB][bk_nb] hits per bucket and row block of groups
     unsigned* bk_base;                     // [bk_nb + 1] first record of a bucket
     uint4* brec2; unsigned* bkg;          // the records in Gaussian order (ray, t, dL/dalpha, +-w) and their Gaussian
-    int bk_shift, bk_nb, bk_ng, bk_rpg;
+    int bk_shift, bk_nb, bk_ng, bk_rpg, bk_cw;   // (bk_cw: see bk_group_ray)
 };
 
 
@@ -815,7 +815,7 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
-    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 1; st->lpt = 1;
+    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 2; st->lpt = 1; st->bk_columns = 1;
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
@@ -918,7 +918,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
-    if (!strcmp(name, "zero_in_prep")) { st->zero_in_prep = value ? 1 : 0; return LRT_OK; }   // A/B switch of the bucketed backward's zero fill (see k_bwd_prep2)
+    if (!strcmp(name, "zero_in_prep")) { st->zero_in_prep = value == 2 ? 2 : value ? 1 : 0; return LRT_OK; }   // A/B switch of the bucketed backward's zero fill (see k_bwd_prep2)
     if (!strcmp(name, "carry_order")) { st->carry = value ? 1 : 0; st->carry_stale = 1; return LRT_OK; }   // 1 (default): builds of an unchanged number of primitives keep the last full sort's order (k_pack + k_make_tree, or the cull index for ray-culled builds); 0: every build sorts (the reference rebuilds its GAS from scratch)
     if (!strcmp(name, "carry_max_age")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_age must be >= 0"); st->carry_max_age = value; return LRT_OK; }   // builds between two full sorts at most (32)
     if (!strcmp(name, "carry_max_inv")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_inv must be >= 0"); st->carry_max_inv = value; return LRT_OK; }   // per mille of neighbour pairs out of Morton order (leaf-sized cells) that makes the next build sort again (20)
@@ -933,6 +933,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fused_tree")) { if (value < 0 || value > 2) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: fused_tree must be 0, 1 or 2"); if (value != 1 && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_tree=%d (the level-by-level / two-launch build) exists in the cross-check library only (-DLRT_LEGACY)", value); st->fused_tree = value; return LRT_OK; }   // 1: records + whole tree in one launch; 2: levels >= 4 in a second launch (k_tree_top); 0: k_make_records + k_level1 + one k_upper launch per level (the round-1..3 build)
     if (!strcmp(name, "fused_hist")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_hist=0 (a histogram launch of its own, k_rs_hist) exists in the cross-check library only (-DLRT_LEGACY)"); st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; return LRT_OK; }
+    if (!strcmp(name, "bk_columns")) { st->bk_columns = value ? 1 : 0; return LRT_OK; }      // 1 (default): the bucketed backward's ray groups are blocks of image columns over all rows (0: runs of consecutive rays)
     if (!strcmp(name, "lpt")) { st->lpt = value ? 1 : 0; st->tile_cost_ready = 0; return LRT_OK; }      // 1 (default): k_fwd_cr4's eight tile queues hold equal shares of the tile lengths of the previous forward of the same tiling (needs learn_slab's per-tile table)   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
@@ -1772,8 +1773,13 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
             if (bucket) {
                 ScopedTimer tm(st, 2, stream);
                 const int hw = H * W;
-                const int rpg = hw <= 16 * BK_MAX_NG ? 16 : (hw + BK_MAX_NG - 1) / BK_MAX_NG;
-                const int ng = (hw + rpg - 1) / rpg;
+                int rpg = hw <= 16 * BK_MAX_NG ? 16 : (hw + BK_MAX_NG - 1) / BK_MAX_NG;
+                int ng = (hw + rpg - 1) / rpg, cw = 0;
+                if (st->fast_valid && st->bk_columns && H <= 4096 && W >= 2) {      // ray groups = blocks of columns over all rows (bk_group_ray): every group the same mix of beams
+                    cw = (W + BK_MAX_NG - 1) / BK_MAX_NG;
+                    while (cw * H < 16 && cw < W) cw++;                              // (tiny images: at least 16 rays per group)
+                    rpg = cw * H; ng = (W + cw - 1) / cw;
+                }
                 const size_t m_words = (size_t)ng * bk_nb, small_words = (size_t)bk_nb * (1 + BK_RB) + 2;
                 if (st->key_cap > st->brec_cap || m_words > st->bk_M_words || small_words > st->bk_small_words) {
                     HIPCHK(hipStreamSynchronize(stream));
@@ -1789,11 +1795,13 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 tp.hit_pk = st->hit_pk; tp.ray_pk = st->ray_pk; tp.hit_wa = st->hit_wa;
                 tp.brec = st->brec; tp.brec2 = st->brec2; tp.bkg = st->bk_g; tp.rec_cap = st->key_cap; tp.bk_M = st->bk_M;
                 tp.bk_aux = st->bk_small; tp.bk_base = st->bk_small + (size_t)BK_RB * bk_nb;
-                tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg;
+                tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg; tp.bk_cw = cw;
                 if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
                 const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
                 tp.fast_prep = st->fast_valid;
                 tp.zero_in_prep = (tp.fast_prep && !st->grads_prezeroed && st->zero_in_prep) ? 1 : 0;
+                // 2: the SH gradients (192 of the 232 MB at M = 16) are cleared by k_bk_sort, a span per workgroup -- a 16-byte aligned table of whole float4s
+                if (tp.zero_in_prep && st->zero_in_prep == 2 && (reinterpret_cast<uintptr_t>(d_shs) & 15u) == 0 && (((size_t)P * M * 3) & 3u) == 0) tp.zero_in_prep = 2;
                 if (lds_nb > 48 * 1024) {
                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
                     if (tp.fast_prep) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_prep2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nb));
