@@ -343,19 +343,22 @@ def main():
             tr1 = ShardedTracer(exchange=args.exchange, world=1, rank=0)
             for kv in args.opt:
                 k_, v_ = kv.split("="); tr1.backend.state.set_option(k_, int(v_))
+            tr1.backend.state.refit_interval = max(args.refit_every, 0)      # the same step as the sharded one
             def step1():
                 tr1.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, rebuild=not args.no_build_in_step, cull_key="bench-frame")
                 tr1.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
             if args.no_build_in_step:
                 tr1.backend.build(t["means"], t["scales"], t["rotations"], t["opacities"])
-            for _ in range(max(args.warmup, 3)):
+            for _ in range(max(args.warmup, 3) + 8):
                 step1()
+            n1_steps = max(args.steps, steps_run)                     # the length of the headline's window
             torch.cuda.synchronize(); t1_ = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(n1_steps):
                 step1()
             torch.cuda.synchronize(); e1_ = time.perf_counter() - t1_
-            value_n1 = {"value": H * W * args.steps / e1_, "unit": "rays/s", "steps": args.steps, "ms_per_step": 1e3 * e1_ / args.steps,
-                        "note": "the unsharded step of the same workload on rank 0's device, timed right behind the sharded window while the other ranks wait"}
+            value_n1 = {"value": H * W * n1_steps / e1_, "unit": "rays/s", "steps": n1_steps, "ms_per_step": 1e3 * e1_ / n1_steps,
+                        "note": "INDICATIVE: the unsharded step of the same workload on rank 0's device, timed right behind the sharded window while the other ranks "
+                                "wait in a barrier; the driver's own N=1 run is the reference for scaling"}
             del tr1
         barrier()
 
@@ -404,6 +407,25 @@ def main():
                     "image_max_abs_diff": float((out_d - out_x).abs().max()),
                     "note": "library option deferred_accum=1 (lrt_backward_accum): no accum atomics in the forward, k_bwd_reduce4 writes the column"}
         del tr_d
+
+    # ---------------- the step with a full Morton sort in EVERY build (library option carry_order=0; the headline's builds keep the order of the last
+    # sort for up to 32 builds -- what a training loop's builds do between optimizer steps -- and sort again when it has decayed)
+    full_sort = None
+    if world == 1 and not args.no_deferred and not args.no_build_in_step and args.refit_every <= 0:
+        st.set_option("carry_order", 0)
+        for _ in range(3):
+            step()
+        st.enable_timing(True); st.get_timing(dev)
+        barrier(); tf = time.perf_counter()
+        for _ in range(max(steps_long // 3, 50)):
+            step()
+        barrier(); el_f = time.perf_counter() - tf
+        ktf = st.get_timing(dev); st.enable_timing(False)
+        st.set_option("carry_order", 1)
+        for _ in range(3):
+            step()
+        full_sort = {"value": H * W * max(steps_long // 3, 50) / el_f, "unit": "rays/s", "steps": max(steps_long // 3, 50), "ms_per_step": 1e3 * el_f / max(steps_long // 3, 50),
+                     "phase_ms": {k_: ktf[k_][0] / max(ktf[k_][1], 1) for k_ in ("build", "fwd", "bwd")}, "note": "library option carry_order=0: every build sorts (k_morton + 3 onesweep passes + k_make_tree)"}
 
     # ---------------- the same step on a frame that changes every iteration (--vary)
     varying = None
@@ -589,7 +611,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "gaussians": int(sc["means"].shape[0]), "rays": [H, W], "sh_degree": deg,
-                       "step": (("LBVH rebuild + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
+                       "step": (("LBVH build (records and tree from the current parameters on the carried Morton order; a full sort every <= 32 builds or when the order has decayed) + " if args.refit_every <= 0 else f"LBVH refit ({args.refit_every} between rebuilds) + ") if not args.no_build_in_step else "") + "forward + backward"
                                + (f" + slab all_gather + gradient exchange '{tr.last_exchange}' (device-side: one pack launch, one all_gather, one apply launch; capacity overflows are flagged on the device and raised by the next step)" if world > 1 else ""),
                        "parallelism": f"azimuth-sector x{world}", "options": args.opt, "dist_backend": backend if world > 1 else None,
                        "gradient_exchange": tr.last_exchange, "via": args.via, "binding": _binding.BACKEND,
@@ -605,13 +627,15 @@ def main():
             res["value_n1"] = value_n1
             res["per_rank_compute_ms"] = per_rank_ms
             res["exchange_ms"] = {"slab_all_gather": phases.get("slab_all_gather"), "gradient_exchange": phases.get("gradient_exchange")}
-            res["speedup_vs_n1"] = (value / value_n1["value"]) if value_n1 else None
+            res["speedup_vs_n1_indicative"] = (value / value_n1["value"]) if (value_n1 and not args.graph and args.via == "direct") else None
         if other is not None:
             res["drop_in_path" if args.via == "direct" else "direct_path"] = {"value": other, "unit": "rays/s", "steps": steps_long}
         if varying is not None:
             res["value_varying"] = varying
         if deferred is not None:
             res["value_deferred_accum"] = deferred
+        if full_sort is not None:
+            res["value_sort_every_build"] = full_sort
         if args.check_sum:
             res["checksums"] = cks
         if world == 1 and not args.no_cpu_baseline:
