@@ -234,7 +234,15 @@ def event_masked_gate(name, sc, o, d, deg, bg, dL, f32_fw, f64_fw, opts=None, ma
         else:
             kinds[kind] = kinds.get(kind, 0) + 1
     if count_only:                                                    # (a comparison run: events counted and certified, nothing masked or asserted)
-        return {"name": name, "event_rays": {"hip": n_hip, "fp32_oracle": n_f32}, "certified": kinds, "uncertified": len(uncertified)}
+        rec_ = {"name": name, "event_rays": {"hip": n_hip, "fp32_oracle": n_f32}, "certified": kinds, "uncertified": len(uncertified), **(extra or {})}
+        try:
+            dd_ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity")
+            os.makedirs(dd_, exist_ok=True)
+            with open(os.path.join(dd_, name + "_events.json"), "w") as f_:
+                json.dump(rec_, f_, indent=1)
+        except OSError:
+            pass
+        return rec_
     # ---- (4) the claim itself on everything else
     masked = ev_hip | ev_f32 | ~usable
     rows = np.nonzero(masked)[0]
