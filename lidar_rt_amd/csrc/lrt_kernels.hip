@@ -171,6 +171,7 @@ static void lrt_rec_free(LrtRec* rec) { if (!rec) return; for (auto& en : rec->c
 
 struct TreeLayout { int L; int cnt[LRT_MAX_LEVELS]; int off[LRT_MAX_LEVELS]; };     // levels 1 .. L of the implicit 8-wide tree: nodes per level, first node of a level
 
+#define LRT_TILE_TABS 64
 struct lrt_state {
     int device;
     int P;               // primitives in the current BVH (-1: none)
@@ -233,7 +234,11 @@ struct lrt_state {
     // SPECULATED from the last completed forward of the same image size (est_hits x 1.125 + 64 k) and decides on the device
     int spec_bwd; int est_valid, est_pending; unsigned est_hits; size_t est_hw, pend_hw; int* status_dev; int bwdq_fresh, last_bwd_spec, spec_margin, defer_errors; hipStream_t last_stream; int* near_list; size_t near_cap;
     int fwd_mode;        // 1 = collect & resolve (default), 0 = legacy 16-slot K-buffer packets
-    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes; int lpt; int tile_cost_ready; int bk_columns;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
+    int tile16_w_log2; float slab0; int* err_flag; float* cr_lists; int cr_blocks_cap; int wg4_per_cu; int c4_qlimit; int fwd_pending; int c4_waves; float* tile_w0; int tile_w0_n; int tile_w0_key[3]; int learn_slab; int root_nodes; int lpt; int tile_cost_ready; int bk_columns;
+    // One learnt tile table (first-slab widths, tile lengths, queue boundaries) PER RAY SET: option ray_set names the set the next forwards trace (a training loop's
+    // frame index; -1 = unnamed).  The live table is tile_w0 / tile_w0_n / tile_w0_key / tile_cost_ready above; the others are parked here (LRU).
+    struct TileTab { float* buf; int n; int key[3]; int cost_ready; long long set; unsigned long long used; } tile_tabs[LRT_TILE_TABS];
+    long long ray_set, tile_tab_live; unsigned long long tile_tab_clock;   // 2 = sorted reduction (default), 1 = replay + atomics, 0 = re-trace
     // HIP-event timing of the build region and of each trace kernel, on the caller's stream
     int timing_enabled;
     struct TimerSlot { hipEvent_t a, b; int kind; };
@@ -815,7 +820,8 @@ lrt_state* lrt_create(int device)
     lrt_state* st = new lrt_state();
     memset(st, 0, sizeof(*st));
     st->device = device; st->P = -1; st->mod = 1.f; st->tile_w_log2 = 4;
-    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 2; st->lpt = 1; st->bk_columns = 1;
+    st->order_P = -1; st->idx_P = -1; st->carry = 1; st->carry_max_age = 32; st->carry_max_inv = 20; st->zero_in_prep = 2; st->lpt = 1; st->bk_columns = 1; st->ray_set = -1; st->tile_tab_live = -1;
+    for (int i = 0; i < LRT_TILE_TABS; i++) { st->tile_tabs[i].buf = nullptr; st->tile_tabs[i].n = 0; st->tile_tabs[i].set = -2; st->tile_tabs[i].used = 0; st->tile_tabs[i].cost_ready = 0; st->tile_tabs[i].key[0] = -1; }
     st->timers = new std::vector<lrt_state::TimerSlot>();
     st->lrec = new LrtRec();
     st->hit_cap = 256; st->hit_cap_auto = 1; st->key_avg = 64; st->spec_cull = 1; st->replay_enabled = 1; st->bwd_mode = 3; st->reduce_mode = 2; st->fwd_mode = 2; st->wg4_per_cu = C4_OCC; st->c4_qlimit = C4_NQ; st->learn_slab = 1; st->defer_colour = 1; st->tile16_w_log2 = 3; st->slab0 = 100.0f; st->own_sort = 2; st->root_nodes = 32; st->fused_tree = 1; st->fused_hist = 1; st->cull_next = -1; st->fuse_fin = 1; st->colour_variant = 1; st->timing_every = 1; st->morton_extra = 4; st->key32 = 1;          // 16-ray tiles 8 wide x 2 high: on a 64 x 2048 sweep the beams are 0.42 deg apart, the columns 0.18 deg, so 8 x 2 is the squarest frustum (-6 % leaf entries against 4 x 4)
@@ -854,7 +860,7 @@ void lrt_destroy(lrt_state* st)
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
     (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk); (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
-    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); rs_free(st->sort_build); rs_free(st->sort_bwd);
+    (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); for (int i = 0; i < LRT_TILE_TABS; i++) (void)hipFree(st->tile_tabs[i].buf); rs_free(st->sort_build); rs_free(st->sort_bwd);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
     lrt_rec_free(st->lrec); delete st->lrec;
@@ -934,6 +940,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fused_hist")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_hist=0 (a histogram launch of its own, k_rs_hist) exists in the cross-check library only (-DLRT_LEGACY)"); st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; return LRT_OK; }
     if (!strcmp(name, "bk_columns")) { st->bk_columns = value ? 1 : 0; return LRT_OK; }      // 1 (default): the bucketed backward's ray groups are blocks of image columns over all rows (0: runs of consecutive rays)
+    if (!strcmp(name, "ray_set")) { st->ray_set = value < 0 ? -1 : value; return LRT_OK; }      // names the ray set of the next forwards (a frame index): the learnt per-tile tables are kept per set (64 sets, least recently used replaced)
     if (!strcmp(name, "lpt")) { st->lpt = value ? 1 : 0; st->tile_cost_ready = 0; return LRT_OK; }      // 1 (default): k_fwd_cr4's eight tile queues hold equal shares of the tile lengths of the previous forward of the same tiling (needs learn_slab's per-tile table)   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }
@@ -1586,6 +1593,23 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
             tp.wg_clk = (st->dbg_wgclk && st->dbg && st->dbg_floats >= 4 * ((size_t)blocks + (size_t)tp.n_tiles)) ? (unsigned long long*)st->dbg : nullptr;
             tp.tile_w0 = nullptr;
             const bool dfr_ = defer && record && st->fuse_fin;
+            if (wg4 && st->learn_slab && st->ray_set != st->tile_tab_live) {
+                // another ray set than the last forward's: park the live table under its name, take this set's own (or the least recently used slot's buffer,
+                // marked unlearnt).  A training loop draws its frames at random: widths and tile lengths learnt on another sensor pose cost the forward 15 %.
+                int slot = -1, lru = 0;
+                for (int i = 0; i < LRT_TILE_TABS; i++) {
+                    if (st->tile_tabs[i].set == st->ray_set) slot = i;
+                    if (st->tile_tabs[i].used < st->tile_tabs[lru].used) lru = i;
+                }
+                lrt_state::TileTab in = (slot >= 0) ? st->tile_tabs[slot] : st->tile_tabs[lru];
+                const int dst = (slot >= 0) ? slot : lru;
+                lrt_state::TileTab& out = st->tile_tabs[dst];         // the live table goes where the incoming one came from
+                out.buf = st->tile_w0; out.n = st->tile_w0_n; memcpy(out.key, st->tile_w0_key, sizeof(out.key)); out.cost_ready = st->tile_cost_ready;
+                out.set = st->tile_tab_live; out.used = ++st->tile_tab_clock;
+                st->tile_w0 = in.buf; st->tile_w0_n = in.n; memcpy(st->tile_w0_key, in.key, sizeof(in.key)); st->tile_cost_ready = in.cost_ready;
+                if (slot < 0) { st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; }      // a replaced set's buffer: contents are somebody else's
+                st->tile_tab_live = st->ray_set;
+            }
             if (wg4 && st->learn_slab) {                             // widths are kept while the image size, tiling and default width stay the same
                 const int key[3] = {H * 65536 + W, tp.tw_log2, (int)(st->slab0 * 1000.f)};
                 if (tp.n_tiles > st->tile_w0_n) {

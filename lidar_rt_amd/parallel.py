@@ -439,6 +439,12 @@ class ShardedTracer:
                 self.backend.build(means, scales, rotations, opacities, mod, cull_rays=cull)
             else:                                                                 # backend without culling (test stand-ins)
                 self.backend.build(means, scales, rotations, opacities, mod)
+        if hasattr(self.backend, "state"):
+            # the library keeps what it learns per tile (first-slab widths, tile lengths -> queue boundaries) per NAMED ray set (option ray_set, 64 sets):
+            # a training loop draws its frames at random, and a table learnt on another sensor pose costs the forward 15 %
+            rs = -1 if cull_key is None else (cull_key if isinstance(cull_key, int) and 0 <= cull_key < 2 ** 30 else (hash(cull_key) & 0x3fffffff))
+            if rs != getattr(self, "_ray_set", None):
+                self.backend.state.set_option("ray_set", rs); self._ray_set = rs
         out_loc, accum_loc = self.backend.forward(self._ro, self._rd, means, scales, rotations, opacities, shs,
                                                   deg, bg, mod)
         self._out_loc, self._accum_loc = out_loc, accum_loc

@@ -157,6 +157,9 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
                                        ("frame", frame, decomp) if isinstance(frame, (int, str)) else None)      # the ray set's name: sizes the culled build (ShardedTracer._cull_sizing)
     else:
         # fused replacement of primitiveCallback(...) + tracer.build_acceleration_structure(vertices, faces, rebuild=True)
+        rs_ = frame if isinstance(frame, int) and 0 <= frame < 2 ** 30 else ((hash(frame) & 0x3fffffff) if isinstance(frame, str) else -1)
+        if rs_ != getattr(tracer_2dgs, "_ray_set", None):            # the frame names the ray set: the library's learnt per-tile tables are kept per set
+            tracer_2dgs.optix_context.set_option("ray_set", rs_); tracer_2dgs._ray_set = rs_
         tracer_2dgs.build_from_gaussians(means3D, scales, rotations, opacity)
         rendered, accum = tracer_2dgs(ray_o=rays_o, ray_d=rays_d, mesh_normals=None, means3D=means3D, grads3D=grads3D,
                                       shs=shs, colors_precomp=None, opacities=opacity, scales=scales,

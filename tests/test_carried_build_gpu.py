@@ -140,3 +140,29 @@ def test_a_stale_cull_index_with_drifted_gaussians_loses_no_primitive(drift):
             assert slots > 0.9 * P, slots                                     # the index knows nothing any more: (nearly) every range
         elif n_slabs == 8:
             assert slots < 0.5 * P, slots                                     # a little drift costs a little culling power, not all of it
+
+
+def test_learnt_tile_tables_are_kept_per_named_ray_set():
+    """Option ray_set names the rays of the next forwards (a training loop's frame index): first-slab widths, tile lengths and the queue boundaries made
+    from them are learnt per name (64 names, least recently used replaced).  They are performance state only: two poses traced in turn under their names,
+    under no name, and under 70 names in rotation (more than the library keeps) give the images of a fresh tracer to the rounding of the slab partial sums."""
+    P, hw = 40_000, (16, 256)
+    sc = scenes.make_scene(P, seed=5, radius_scale=0.3)
+    o, d = scenes.kitti_rays(*hw); dL = scenes.upstream_grad(*hw)
+    c_, s_ = np.cos(0.7), np.sin(0.7)
+    R = np.array([[c_, -s_, 0.0], [s_, c_, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    poses = [(o, d), (np.ascontiguousarray(o + np.float32([0.3, -0.2, 0.05])), np.ascontiguousarray(d @ R.T))]
+    ref = [_step(_tracer(), sc, po, pd, dL) for po, pd in poses]
+    named, unnamed, many = _tracer(), _tracer(), _tracer()
+    for it in range(12):
+        k = it & 1
+        named.optix_context.set_option("ray_set", 100 + k)
+        many.optix_context.set_option("ray_set", it * 7 % 70 if it < 10 else 100 + k)
+        for tr in (named, unnamed, many):
+            got = _step(tr, sc, *poses[k], dL)
+            np.testing.assert_allclose(got["out"], ref[k]["out"], rtol=2e-6, atol=1e-7)
+            np.testing.assert_array_equal(got["accum"] > 0, ref[k]["accum"] > 0)
+            for g in GRADS:
+                assert rel_l2(got["grads"][g], ref[k]["grads"][g]) < 5e-6, (it, g)
+    for tr in (named, unnamed, many):
+        tr.check(DEV)
