@@ -171,7 +171,7 @@ static void lrt_rec_free(LrtRec* rec) { if (!rec) return; for (auto& en : rec->c
 
 struct TreeLayout { int L; int cnt[LRT_MAX_LEVELS]; int off[LRT_MAX_LEVELS]; };     // levels 1 .. L of the implicit 8-wide tree: nodes per level, first node of a level
 
-#define LRT_TILE_TABS 64
+#define LRT_TILE_TABS 256
 struct lrt_state {
     int device;
     int P;               // primitives in the current BVH (-1: none)
@@ -940,7 +940,7 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "fused_hist")) { if (!value && !LRT_HAS_LEGACY) LRT_FAIL(LRT_ERR_STATE, "lrt_set_option: fused_hist=0 (a histogram launch of its own, k_rs_hist) exists in the cross-check library only (-DLRT_LEGACY)"); st->fused_hist = value ? 1 : 0; return LRT_OK; }   // 0: the radix sort counts its digit histograms in a launch of its own (k_rs_hist)
     if (!strcmp(name, "learn_slab")) { st->learn_slab = value ? 1 : 0; st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; return LRT_OK; }
     if (!strcmp(name, "bk_columns")) { st->bk_columns = value ? 1 : 0; return LRT_OK; }      // 1 (default): the bucketed backward's ray groups are blocks of image columns over all rows (0: runs of consecutive rays)
-    if (!strcmp(name, "ray_set")) { st->ray_set = value < 0 ? -1 : value; return LRT_OK; }      // names the ray set of the next forwards (a frame index): the learnt per-tile tables are kept per set (64 sets, least recently used replaced)
+    if (!strcmp(name, "ray_set")) { st->ray_set = value < 0 ? -1 : value; return LRT_OK; }      // names the ray set of the next forwards (a frame index): the learnt per-tile tables are kept per set (256 sets, least recently used replaced)
     if (!strcmp(name, "lpt")) { st->lpt = value ? 1 : 0; st->tile_cost_ready = 0; return LRT_OK; }      // 1 (default): k_fwd_cr4's eight tile queues hold equal shares of the tile lengths of the previous forward of the same tiling (needs learn_slab's per-tile table)   // per-tile first-slab width carried between frames
     if (!strcmp(name, "c4_waves")) { if (value != 0 && value != 4 && value != 8 && value != 16) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: c4_waves must be 0 (auto), 4, 8 or 16"); st->c4_waves = value; return LRT_OK; }
     if (!strcmp(name, "wg4_per_cu")) { if (value < 1 || value > 8) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: wg4_per_cu must be 1..8"); st->wg4_per_cu = value; return LRT_OK; }

@@ -440,7 +440,7 @@ class ShardedTracer:
             else:                                                                 # backend without culling (test stand-ins)
                 self.backend.build(means, scales, rotations, opacities, mod)
         if hasattr(self.backend, "state"):
-            # the library keeps what it learns per tile (first-slab widths, tile lengths -> queue boundaries) per NAMED ray set (option ray_set, 64 sets):
+            # the library keeps what it learns per tile (first-slab widths, tile lengths -> queue boundaries) per NAMED ray set (option ray_set, 256 sets):
             # a training loop draws its frames at random, and a table learnt on another sensor pose costs the forward 15 %
             rs = -1 if cull_key is None else (cull_key if isinstance(cull_key, int) and 0 <= cull_key < 2 ** 30 else (hash(cull_key) & 0x3fffffff))
             if rs != getattr(self, "_ray_set", None):

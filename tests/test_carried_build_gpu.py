@@ -144,8 +144,8 @@ def test_a_stale_cull_index_with_drifted_gaussians_loses_no_primitive(drift):
 
 def test_learnt_tile_tables_are_kept_per_named_ray_set():
     """Option ray_set names the rays of the next forwards (a training loop's frame index): first-slab widths, tile lengths and the queue boundaries made
-    from them are learnt per name (64 names, least recently used replaced).  They are performance state only: two poses traced in turn under their names,
-    under no name, and under 70 names in rotation (more than the library keeps) give the images of a fresh tracer to the rounding of the slab partial sums."""
+    from them are learnt per name (256 names, least recently used replaced).  They are performance state only: two poses traced in turn under their names,
+    under no name, and under 300 names in rotation (more than the library keeps) give the images of a fresh tracer to the rounding of the slab partial sums."""
     P, hw = 40_000, (16, 256)
     sc = scenes.make_scene(P, seed=5, radius_scale=0.3)
     o, d = scenes.kitti_rays(*hw); dL = scenes.upstream_grad(*hw)
@@ -156,13 +156,22 @@ def test_learnt_tile_tables_are_kept_per_named_ray_set():
     named, unnamed, many = _tracer(), _tracer(), _tracer()
     for it in range(12):
         k = it & 1
-        named.optix_context.set_option("ray_set", 100 + k)
-        many.optix_context.set_option("ray_set", it * 7 % 70 if it < 10 else 100 + k)
-        for tr in (named, unnamed, many):
+        named.optix_context.set_option("ray_set", 1000 + k)
+        for tr in (named, unnamed):
             got = _step(tr, sc, *poses[k], dL)
             np.testing.assert_allclose(got["out"], ref[k]["out"], rtol=2e-6, atol=1e-7)
             np.testing.assert_array_equal(got["accum"] > 0, ref[k]["accum"] > 0)
             for g in GRADS:
                 assert rel_l2(got["grads"][g], ref[k]["grads"][g]) < 5e-6, (it, g)
+    for it in range(310):                                                     # 300 names in rotation, then the first ones again (replaced meanwhile)
+        k = it & 1
+        many.optix_context.set_option("ray_set", it % 300)
+        if it % 31 == 0 or it >= 300:
+            got = _step(many, sc, *poses[k], dL)
+            np.testing.assert_allclose(got["out"], ref[k]["out"], rtol=2e-6, atol=1e-7)
+        else:                                                                 # (forward only: the table is taken and learnt in the forward)
+            t_ = {q: torch.as_tensor(np.asarray(v, np.float32), device=DEV) for q, v in sc.items()}
+            many(torch.as_tensor(poses[k][0], device=DEV), torch.as_tensor(poses[k][1], device=DEV), None, t_["means"], torch.zeros_like(t_["means"]), shs=t_["shs"],
+                 opacities=t_["opacities"], scales=t_["scales"], rotations=t_["rotations"], tracer_settings=settings(scenes.BG_DEFAULT, 3))
     for tr in (named, unnamed, many):
         tr.check(DEV)
