@@ -173,8 +173,14 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
  * 2 sorted replay, 1 replay + atomics, 0 re-trace like backward.cu:513); defer_colour; hit_cap (composited hits recorded per ray, 256);
  * spec_bwd; defer_errors; refine_ties (1: hits closer than 2 ulp are ordered by their fp64 distance); lag_bounds (1: Morton box of
  * the previous build); root_nodes (32); slab0_mm (first depth slab, 100000); c4_waves (waves per 16-ray tile of the forward: 0 = by the
- * number of tiles [default: 16 up to 1536 tiles, 8 up to 3072 or for heavy tiles, else 4], or 4 / 8 / 16); wg4_per_cu (resident 4-wave
- * workgroups per CU, 5); the full list is lrt_set_option in lrt_kernels.hip. */
+ * number of tiles [default: 8 up to 3072 tiles or for heavy tiles, 16 for up to 1536 dense tiles, else 4], or 4 / 8 / 16); wg4_per_cu (resident 4-wave
+ * workgroups per CU, 5).  Round 6: deferred_accum (1: a training forward leaves `accum` zero, its backward completes it: lrt_backward_accum);
+ * carry_order (1 [default]: a build of an unchanged P keeps the Morton order of the last full sort; carry_max_age 32 builds, carry_max_inv 20 per mille
+ * of neighbours out of order make the next build sort again; 0: sort in every build like the reference's rebuild); ray_set (N >= 0 names the rays of
+ * the next forwards -- a training loop's frame index: what the forward learns per tile (first-slab widths, tile lengths, queue boundaries) is kept per
+ * name, 256 names; -1 [default]: unnamed); lpt, learn_slab, bk_columns, zero_in_prep (A/B switches of the schedule and of the backward's ray groups /
+ * zero fill: DESIGN.md 4.2 / 4.3).  bwd_mode 1 / 2, defer_colour 0 and fused_tree 0 / 2 exist in the cross-check library only (lrt_has_legacy).
+ * The full list is lrt_set_option in lrt_kernels.hip. */
 int lrt_set_option(lrt_state* st, const char* name, int value);
 /* Current value of an option (hit_cap, hit_cap_auto, fwd_mode, bwd_mode, reduce_mode, defer_colour, c4_waves): hit_cap can grow
  * by itself, see lrt_kernels.hip.  Two read-only names: "cull_last" (primitives the last culled build kept) and "near_rays_last" (rays the
