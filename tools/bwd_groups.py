@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer tool: composited hits per image row of S1M and per ray group of the bucketed backward under two groupings (runs of consecutive rays;
+blocks of columns over strided rows): the imbalance k_bk_count / k_bwd_prep2 see with one workgroup per group."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

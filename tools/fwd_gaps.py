@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Developer tool: where the workgroups of one k_fwd_cr4 launch (S1M, production instantiation, option dbg_wgclk) spend their time outside tiles:
+workgroup start -> first tile, tile end -> next tile start, last tile -> workgroup end; sums against the launch x slots; when the workgroups' last tiles end.
+env LPT=0/1 (tile queues cut by work and rows longest first), LRT_OPTS as elsewhere."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

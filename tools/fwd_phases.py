@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer tool: inside a tile of k_fwd_cr4 (S1M, STATISTICS instantiation, two workgroups per CU): mean length, Phase A / Phase B / rest, slab passes,
+node and leaf rounds, tests per tile; the same by tile row."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
