@@ -210,6 +210,8 @@ struct lrt_state {
     LrtRec* lrec; int graph_mode;   // option "graph": the launch sequence of every API call is recorded and replayed from a HIP graph (see LrtRec)
     int cone_ev_due;     // build: record cone_ev once the call's launches have been issued
     int deferred_accum; float* acc_ptr; long long acc_serial; int acc_pending;   // option deferred_accum: a training forward leaves `accum` all-zero, the backward of that forward writes the per-Gaussian sums of composite weights (forward.cu:268) into it
+    int deterministic;   // option deterministic: gradient sums in a fixed order (a Gaussian's records by ray, the pieces of a run that crosses waves in wave order), no history in the forward
+    float* det_part; size_t det_part_floats;   // ... the pieces: two 64-float rows per wave of k_bwd_reduce4
     int zero_in_prep;    // 1 (default): the bucketed backward clears the gradient tensors inside k_bwd_prep2 (streaming) instead of rows of zeros from k_bk_sort
     int grads_prezeroed; // 1: the caller keeps the gradient tensors all-zero on entry to lrt_backward (it clears the rows of the previous step by list): no zero rows, no memsets
     int timing_every; unsigned timer_calls[4];      // see ScopedTimer
@@ -279,6 +281,7 @@ struct TraceParams {
     float2* hit_wa;        // deferred-colour forward: per recorded hit (composite weight, unclamped op*G)
     int prezeroed;         // backward: the gradient tensors are all-zero on entry (option grads_prezeroed): no zero rows are stored
     int zero_in_prep;      // backward: k_bwd_prep2 clears the gradient tensors whole (round 6), k_bk_sort stores no rows of zeros
+    int deterministic, det_bm_words; float* det_part;   // backward, option deterministic (det_bm_words: words of k_bk_sort's ray bitmap, 0 = the image is too large for it): k_bk_sort orders every Gaussian's run by ray (into brec), k_bwd_reduce4 stores the pieces of runs that cross its waves to det_part, k_bwd_fixup adds them in wave order
     int fast_prep;         // backward: hit_wa / hit_pk hold the forward's alpha and colour of every recorded hit
     // sorted-reduction backward: dense (g << 32 | id) keys appended by the forward, per-hit scalars from k_bwd_prepare
     unsigned long long* hit_keys; unsigned* hit_count; unsigned key_cap; const unsigned* hit_off; int id_bits;
@@ -859,7 +862,7 @@ void lrt_destroy(lrt_state* st)
     for (void* q : olds) (void)hipFree(q);
     for (auto& t : *st->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     (void)hipFree(st->hit_t); (void)hipFree(st->hit_g); (void)hipFree(st->hit_n);
-    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk); (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
+    (void)hipFree(st->hit_keys); (void)hipFree(st->hit_keys_sorted); (void)hipFree(st->hit_pk); (void)hipFree(st->det_part); (void)hipFree(st->brec); (void)hipFree(st->brec2); (void)hipFree(st->bk_g); (void)hipFree(st->bk_M); (void)hipFree(st->bk_small);
     (void)hipFree(st->ray_pk); (void)hipFree(st->bsort_tmp); (void)hipFree(st->hit_off); (void)hipFree(st->scan_tmp); (void)hipFree(st->hit_wa); (void)hipFree(st->cr_lists); (void)hipFree(st->tile_w0); for (int i = 0; i < LRT_TILE_TABS; i++) (void)hipFree(st->tile_tabs[i].buf); rs_free(st->sort_build); rs_free(st->sort_bwd);
     (void)hipHostFree(st->hit_ovf_host); (void)hipEventDestroy(st->hit_ev); (void)hipFree(st->near_list);
     delete st->timers;
@@ -872,7 +875,7 @@ int lrt_get_option(lrt_state* st, const char* name, int* value)
     if (!st || !name || !value) LRT_FAIL(LRT_ERR_ARG, "lrt_get_option: null argument");
     const struct { const char* n; int v; } tab[] = {{"hit_cap", st->hit_cap}, {"hit_cap_auto", st->hit_cap_auto}, {"fwd_mode", st->fwd_mode},
         {"bwd_mode", st->bwd_mode}, {"reduce_mode", st->reduce_mode}, {"defer_colour", st->defer_colour}, {"c4_waves", st->c4_waves}, {"spec_bwd", st->spec_bwd}, {"last_bwd_speculative", st->last_bwd_spec},
-        {"graph", st->graph_mode}, {"deferred_accum", st->deferred_accum}, {"carry_order", st->carry}, {"carry_age", st->carry_age}, {"carry_inversions_last", (int)st->carry_inv_last}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
+        {"graph", st->graph_mode}, {"deferred_accum", st->deferred_accum}, {"deterministic", st->deterministic}, {"carry_order", st->carry}, {"carry_age", st->carry_age}, {"carry_inversions_last", (int)st->carry_inv_last}, {"graph_hits", (int)(st->lrec->hits & 0x7fffffff)}, {"graph_captures", (int)(st->lrec->captures & 0x7fffffff)}};
     for (const auto& e : tab) if (!strcmp(name, e.n)) { *value = e.v; return LRT_OK; }
     if (!strcmp(name, "cull_last")) {                        // primitives the last culled build kept (raw: also those a too small speculative size lost); -1 = none yet
         DeviceGuard dg(st->device);
@@ -924,6 +927,15 @@ int lrt_set_option(lrt_state* st, const char* name, int value)
     if (!strcmp(name, "lag_bounds")) { st->lag_bounds = value ? 1 : 0; st->bounds_ready = 0; return LRT_OK; }   // 1 (default): the Morton grid of a build is laid over the PREVIOUS build's box (no bounds pass); 0: k_bounds per build
     if (!strcmp(name, "build_pack")) { st->no_pack = value ? 0 : 1; return LRT_OK; }   // 0: k_make_records gathers the four parameter arrays directly
     if (!strcmp(name, "graph")) { st->graph_mode = value ? 1 : 0; return LRT_OK; }   // 1: every API call's launches are replayed from a HIP graph (recorded, fingerprinted, instantiated once per distinct sequence)
+    if (!strcmp(name, "deterministic")) {      // 1: bit-reproducible results that do not depend on earlier calls: gradient sums in a fixed order (k_bk_sort, k_bwd_fixup) and a forward
+        // without learnt state (first-slab widths, carried Morton order, the previous build's box).  The caller adds deferred_accum (the forward's hit weights are float atomics).
+        const int was = st->deterministic;
+        st->deterministic = value ? 1 : 0;
+        if (value || was) {      // on: the three learnt tables off; off again: back to their defaults
+            st->learn_slab = value ? 0 : 1; st->tile_w0_key[0] = -1; st->tile_cost_ready = 0; st->carry = value ? 0 : 1; st->carry_stale = 1; st->lag_bounds = value ? 0 : 1; st->bounds_ready = 0;
+        }
+        return LRT_OK;
+    }
     if (!strcmp(name, "zero_in_prep")) { st->zero_in_prep = value == 2 ? 2 : value ? 1 : 0; return LRT_OK; }   // A/B switch of the bucketed backward's zero fill (see k_bwd_prep2)
     if (!strcmp(name, "carry_order")) { st->carry = value ? 1 : 0; st->carry_stale = 1; return LRT_OK; }   // 1 (default): builds of an unchanged number of primitives keep the last full sort's order (k_pack + k_make_tree, or the cull index for ray-culled builds); 0: every build sorts (the reference rebuilds its GAS from scratch)
     if (!strcmp(name, "carry_max_age")) { if (value < 0) LRT_FAIL(LRT_ERR_ARG, "lrt_set_option: carry_max_age must be >= 0"); st->carry_max_age = value; return LRT_OK; }   // builds between two full sorts at most (32)
@@ -1448,11 +1460,23 @@ int lrt_forward(lrt_state* st, int H, int W, const float* ray_o, const float* ra
 {
     if (!st) LRT_FAIL(LRT_ERR_ARG, "lrt_forward: null state");
     DeviceGuard dg(st->device);
-    rec_begin(st, stream_);
-    int issued = 0;
-    int rc = forward_impl(st, H, W, ray_o, ray_d, P, M, deg, shs, bg, training, out9, out_i32, accum, stream_, &issued);
-    rc = rec_end(st, rc, (hipStream_t)stream_);
-    if (rc == LRT_OK && issued) HIPCHK(hipEventRecord(st->hit_ev, (hipStream_t)stream_));      // behind the call's last launch: the status block is complete
+    int rc = LRT_OK;
+    for (int attempt = 0; ; ++attempt) {
+        rec_begin(st, stream_);
+        int issued = 0;
+        rc = forward_impl(st, H, W, ray_o, ray_d, P, M, deg, shs, bg, training, out9, out_i32, accum, stream_, &issued);
+        rc = rec_end(st, rc, (hipStream_t)stream_);
+        if (rc == LRT_OK && issued) HIPCHK(hipEventRecord(st->hit_ev, (hipStream_t)stream_));      // behind the call's last launch: the status block is complete
+        // Option deterministic: a hit record that was too small for the frame sends its rays through the overflow list (colours added in the order of
+        // arrival) and the backward through the re-tracing kernel (float atomics), and the record's size is a piece of history (it doubles after an
+        // overflow).  Such a forward WAITS for its status words and runs again with the grown record until the frame fits: its results never come
+        // from a fallback, whatever the state has seen before.  (One host wait per training forward: the price of the option.)
+        if (!(st->deterministic && training && rc == LRT_OK && issued && st->est_pending && attempt < 8)) break;
+        HIPCHK(hipEventSynchronize(st->hit_ev));
+        const int cap0 = st->hit_cap, avg0 = st->key_avg;
+        (void)absorb_status(st);
+        if (st->hit_cap == cap0 && st->key_avg == avg0) break;
+    }
     return rc;
 }
 static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const float* ray_d, int P, int M, int deg,
@@ -1820,6 +1844,18 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
                 tp.brec = st->brec; tp.brec2 = st->brec2; tp.bkg = st->bk_g; tp.rec_cap = st->key_cap; tp.bk_M = st->bk_M;
                 tp.bk_aux = st->bk_small; tp.bk_base = st->bk_small + (size_t)BK_RB * bk_nb;
                 tp.bk_shift = bk_shift; tp.bk_nb = (int)bk_nb; tp.bk_ng = ng; tp.bk_rpg = rpg; tp.bk_cw = cw;
+                if (st->deterministic) {
+                    const size_t part_floats = 128 * (((size_t)st->key_cap + 63) / 64);
+                    if (part_floats > st->det_part_floats) {
+                        HIPCHK(hipStreamSynchronize(stream));
+                        (void)hipFree(st->det_part); st->det_part = nullptr; st->det_part_floats = 0;
+                        HIPCHK(hipMalloc(&st->det_part, part_floats * sizeof(float)));
+                        st->det_part_floats = part_floats;
+                    }
+                    tp.deterministic = 1; tp.det_part = st->det_part;
+                    const size_t bm_words = ((size_t)H * W + 31) / 32;
+                    if ((bm_words + 256) * sizeof(unsigned) + (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned) <= 48 * 1024) tp.det_bm_words = (int)bm_words;
+                }
                 if (spec) { tp.guard = 1; tp.n_hits_dev = st->hit_count; tp.n_spec = st->key_cap; }     // any complete record that fits is taken
                 const size_t lds_nb = (size_t)bk_nb * sizeof(unsigned), lds_sort = (2 * ((size_t)1 << bk_shift) + 1) * sizeof(unsigned);
                 tp.fast_prep = st->fast_valid;
@@ -1839,8 +1875,10 @@ static int backward_impl(lrt_state* st, int H, int W, const float* ray_o, const 
 #ifdef LRT_LEGACY
                 else lrt_launch(st->lrec, (k_bwd_prep<false, true>), dim3(ng), dim3(1024), lds_nb, stream, tp);
 #endif
-                lrt_launch(st->lrec, k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort, stream, tp);
+                lrt_launch(st->lrec, k_bk_sort, dim3((unsigned)bk_nb), dim3(256), lds_sort + (tp.det_bm_words ? ((size_t)tp.det_bm_words + 256) * sizeof(unsigned) : 0), stream, tp);
+                if (tp.deterministic) tp.brec2 = st->brec;      // k_bk_sort's second pass left the records, every run in ray order, in the bucket's (dead) span of brec
                 lrt_launch(st->lrec, k_bwd_reduce4, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
+                if (tp.deterministic) lrt_launch(st->lrec, k_bwd_fixup, dim3((unsigned)(((size_t)st->key_cap + 255) / 256)), dim3(256), 0, stream, tp);
                 if (spec) {      // the fallback for a record that turns out unusable: re-trace (returns at once otherwise; k_bk_sort left rows of zeros)
                     tp.guard = 2;
                     HIPCHK(hipGetLastError());

@@ -73,18 +73,26 @@ class _Tracer(torch.autograd.Function):
 
 
 class Tracer(nn.Module):
-    def __init__(self, deferred_accum: bool = False) -> None:
+    def __init__(self, deferred_accum: bool = False, deterministic: bool = False) -> None:
         """deferred_accum (addition; the reference's constructor takes no argument): in training mode with a backward to follow, the
         forward returns `accum` ALL-ZERO and ``loss.backward()`` fills the SAME tensor (the per-Gaussian sums of composite weights,
         forward.cu:268) -- the reference's loop reads them only after the backward (train.py:156,219), and the forward saves one float
-        atomic per composited hit.  Evaluation-mode forwards and forwards without a backward stay exact at once."""
+        atomic per composited hit.  Evaluation-mode forwards and forwards without a backward stay exact at once.
+        deterministic (addition): bit-reproducible results that do not depend on earlier calls -- the gradient sums are taken in a fixed
+        order (library option ``deterministic``: a Gaussian's records by ray, the pieces of a run in wave order), the forward keeps no
+        learnt state (first-slab widths, carried Morton order, the previous build's box) and the hit weights come from the backward
+        (implies deferred_accum: the forward's are float atomics).  Slower (build and forward without their learnt tables, a second pass
+        over the records); a resumed training run then repeats the uninterrupted one bit for bit."""
         super().__init__()
         # the reference creates its OptiX context here (zero-argument ctor, module-level singleton in
         # lib/gaussian_renderer/__init__.py:11); ours is a cheap host object, device state is created lazily
         self.optix_context = _C.OptiXStateWrapper("")
         self.vertices = None
         self.deferred_checks = False     # True: forwards without a backward do not wait for the trace; call check() once per batch
-        self.deferred_accum = bool(deferred_accum)
+        self.deterministic = bool(deterministic)
+        self.deferred_accum = bool(deferred_accum) or self.deterministic
+        if self.deterministic:
+            self.optix_context.set_option("deterministic", 1)
         if self.deferred_accum:
             self.optix_context.deferred_accum = True
             self.optix_context.set_option("deferred_accum", 1)

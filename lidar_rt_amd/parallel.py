@@ -132,7 +132,7 @@ class ShardedTracer:
     """Traces one frame sharded by azimuth sector over ``dist``'s world."""
 
     def __init__(self, backend=None, group=None, exchange: str = "sparse", world: Optional[int] = None, rank: Optional[int] = None,
-                 deferred_accum: bool = False):
+                 deferred_accum: bool = False, deterministic: bool = False):
         """deferred_accum: the local forward leaves the hit weights `accum` all-zero and the local BACKWARD writes them (library option
         deferred_accum, lrt_backward_accum) -- straight into the flat exchange buffer when there is an exchange.  A training step reads the
         weights after the backward only (train.py:156,219); callers that need them from the forward keep the default.
@@ -148,7 +148,10 @@ class ShardedTracer:
         self.last_exchange = None                      # what the last backward used: "dense" | "sparse" | "owner" | None
         self.last_owner: Optional[torch.Tensor] = None  # (P,) int32 owner map of the last "owner" exchange
         self.backend = backend if backend is not None else HipBackend()
-        self.deferred_accum = bool(deferred_accum) and isinstance(self.backend, HipBackend)
+        self.deterministic = bool(deterministic) and isinstance(self.backend, HipBackend)      # library option deterministic (see Tracer): this rank's sums in a fixed order
+        if self.deterministic:
+            self.backend.state.set_option("deterministic", 1)
+        self.deferred_accum = (bool(deferred_accum) or self.deterministic) and isinstance(self.backend, HipBackend)
         if self.deferred_accum:
             self.backend.state.set_option("deferred_accum", 1)
         self.group = group

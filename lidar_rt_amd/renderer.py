@@ -34,6 +34,8 @@ def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 # loss.backward() fills the same tensor -- train.py reads them after the backward only (:156, :219) -- which takes one float atomic per
 # composited hit out of the forward (Tracer(deferred_accum=True), lrt_backward_accum).  Evaluation renders are exact at once either way.
 deferred_accum = False
+# Bit-reproducible training (addition): Tracer(deterministic=True) -- gradient sums in a fixed order, no learnt state in the forward; implies deferred_accum.
+deterministic = False
 
 use_fused_preprocess = True   # module switch: False forces the getter chain of the reference (used by the tests)
 
@@ -99,8 +101,8 @@ def raytracing(frame, gaussian_assets, sensor, background, args, scaling_modifie
                decomp=False):
     global tracer_2dgs
     if sharded is None:
-        if tracer_2dgs is None or tracer_2dgs.deferred_accum != bool(deferred_accum):
-            tracer_2dgs = Tracer(deferred_accum=bool(deferred_accum))
+        if tracer_2dgs is None or tracer_2dgs.deferred_accum != (bool(deferred_accum) or bool(deterministic)) or tracer_2dgs.deterministic != bool(deterministic):
+            tracer_2dgs = Tracer(deferred_accum=bool(deferred_accum), deterministic=bool(deterministic))
         # opt.bvh_refit_interval = K > 0: K refits (lrt_refit: same order and topology, new records and boxes) between full LBVH
         # builds while the number of Gaussians is unchanged; results do not depend on it.  0 = rebuild every call (the reference)
         tracer_2dgs.optix_context.refit_interval = int(getattr(getattr(args, "opt", None), "bvh_refit_interval", 0) or 0)

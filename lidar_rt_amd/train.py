@@ -47,8 +47,9 @@ def run(args) -> dict:
         backend = os.environ.get("LRT_DIST_BACKEND", "nccl")
         dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
         from .parallel import ShardedTracer
-        renderer.sharded = ShardedTracer(exchange="sparse", deferred_accum=not args.exact_accum)
+        renderer.sharded = ShardedTracer(exchange="sparse", deferred_accum=not args.exact_accum, deterministic=args.deterministic)
     renderer.deferred_accum = not args.exact_accum       # the loop reads the hit weights after loss.backward() only (train.py:156,219)
+    renderer.deterministic = bool(args.deterministic)    # gradient sums in a fixed order, a forward without learnt state: a resumed run repeats the uninterrupted one bit for bit
 
     seq = sequence.load_sequence(args.data, dev)
     opt = training.default_options()
@@ -107,7 +108,12 @@ def main(argv=None) -> int:
     ap.add_argument("--opt", action="append", default=[], help="training option name=value (lidar_rt_amd.training.default_options)")
     ap.add_argument("--exact-accum", action="store_true", help="hit weights complete at the forward (the reference's contract) instead of written by "
                     "the backward (renderer.deferred_accum, the default here: the loop reads them after the backward only)")
+    ap.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (Tracer(deterministic=True): the backward adds a Gaussian's records up by ray and "
+                    "the pieces of long runs in order, the forward keeps no learnt tables): ~1.4 x the tracer time; a run resumed from a checkpoint then equals the "
+                    "uninterrupted one bit for bit (with lambda_cd = 0: the Chamfer backward adds with float atomics)")
     args = ap.parse_args(argv)
+    if args.exact_accum and args.deterministic:
+        ap.error("--deterministic takes the hit weights from the backward (the forward's are float atomics): not with --exact-accum")
     if args.out is None:
         args.out = os.path.join(args.data, "output")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

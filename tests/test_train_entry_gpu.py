@@ -84,3 +84,38 @@ def test_fifty_iterations_from_disk_and_a_resume_from_the_checkpoint(tmp_path):
             apart = ((x - y).abs() > one_step).double().mean()
             assert float(apart) < 0.05, (i, float(apart))
             assert float((x - y).abs().median()) < 0.1 * one_step, (i, float((x - y).abs().median()))
+
+
+def test_a_deterministic_run_resumed_from_its_checkpoint_repeats_the_uninterrupted_run_bit_for_bit(tmp_path):
+    """--deterministic (Tracer(deterministic=True)): the gradient sums are taken in a fixed order and the forward keeps no learnt state, so a second
+    process resumed from the iteration-12 checkpoint must arrive at the SAME iteration-24 checkpoint -- every parameter and Adam moment bit for bit,
+    every logged loss equal, the same clone / split / prune counts in the densifications on both sides of the checkpoint -- as the run that was never
+    interrupted (train.py:67-447's resume).  All loss terms at the reference's weights (the Chamfer term carries no gradient, as in
+    the reference: lidar_sensor.py:182-183)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_sequence
+    data = str(tmp_path / "seq")
+    make_sequence.make("kitti360_dynamic", data, n_frames=4, scale=0.1)
+    common = ["--data", data, "--log-every", "1", "--save-every", "12", "--max-points", "60000", "--deterministic",
+              "--opt", "densify_from_iter=4", "--opt", "densification_interval=8"]                  # densifications at 8, 16 and 24
+    run = lambda out, extra: subprocess.run([sys.executable, "-m", "lidar_rt_amd.train", "--out", out] + common + extra, cwd=REPO, capture_output=True,
+                                            text=True, timeout=1500)
+    a = run(str(tmp_path / "a"), ["--iters", "24"])
+    assert a.returncode == 0, a.stdout[-2000:] + a.stderr[-3000:]
+    b = run(str(tmp_path / "b"), ["--iters", "24", "--resume", str(tmp_path / "a" / "chkpnt12.pth")])
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-3000:]
+    rows_a = [json.loads(l) for l in a.stdout.splitlines() if l.startswith("{")]
+    rows_b = [json.loads(l) for l in b.stdout.splitlines() if l.startswith("{")]
+    tail_a = [r for r in rows_a if r["iteration"] > 12]
+    assert [r["iteration"] for r in rows_b] == [r["iteration"] for r in tail_a] and len(rows_b) == 12
+    for ra, rb in zip(tail_a, rows_b):
+        assert ra["frame"] == rb["frame"] and ra["points"] == rb["points"] and ra["loss"] == rb["loss"], (ra, rb)
+    pa, pb = _load(tmp_path / "a" / "chkpnt24.pth")[0], _load(tmp_path / "b" / "chkpnt24.pth")[0]
+    assert len(pa) == len(pb) == 9
+    assert len({r["points"] for r in rows_a}) > 1, [r["points"] for r in rows_a]                    # the densifications changed the number of Gaussians
+    for ga, gb in zip(pa, pb):
+        for i in (1, 2, 3, 4, 5, 6, 8, 9):
+            assert torch.equal(ga[i].detach().cpu(), gb[i].detach().cpu()), i
+        for k, st in ga[10]["state"].items():
+            for n in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(gb[10]["state"][k][n].cpu(), st[n].cpu()), (k, n)
