@@ -408,6 +408,32 @@ def main():
                     "note": "library option deferred_accum=1 (lrt_backward_accum): no accum atomics in the forward, k_bwd_reduce4 writes the column"}
         del tr_d
 
+    # ---------------- the bit-reproducible step (ShardedTracer(deterministic=True) / train --deterministic): gradient sums in a fixed order (a second pass over the
+    # records in k_bk_sort, k_bwd_fixup), a forward without learnt tables that waits for its status words.  NOT the headline: what reproducibility costs.
+    determ = None
+    if world == 1 and not args.no_deferred and not args.no_build_in_step and args.refit_every <= 0:
+        tr_t = ShardedTracer(exchange=args.exchange, deterministic=True)
+        tr_t.backend.state.set_option("timing_every", max(1, args.time_every))
+
+        def step_det():
+            out_, _ = tr_t.forward(ray_o, ray_d, t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, cull_key="bench-frame")
+            return out_, tr_t.backward(t["means"], t["scales"], t["rotations"], t["opacities"], t["shs"], deg, bg, dL)
+        for _ in range(max(args.warmup, 3)):
+            out_t0, g_t0 = step_det()
+        g_t0 = {k_: v_.clone() for k_, v_ in g_t0.items()}; out_t0 = out_t0.clone()
+        n_t = max(steps_long // 3, 50)
+        tr_t.backend.state.enable_timing(True)
+        barrier(); tt = time.perf_counter()
+        for _ in range(n_t):
+            out_t, g_t = step_det()
+        barrier(); el_t = time.perf_counter() - tt
+        ktt = tr_t.backend.state.get_timing(dev); tr_t.backend.state.enable_timing(False)
+        determ = {"value": H * W * n_t / el_t, "unit": "rays/s", "steps": n_t, "ms_per_step": 1e3 * el_t / n_t,
+                  "phase_ms": {k_: ktt[k_][0] / max(ktt[k_][1], 1) for k_ in ("build", "fwd", "bwd")},
+                  "bit_identical_over_the_window": bool(torch.equal(out_t, out_t0) and all(torch.equal(g_t[k_], g_t0[k_]) for k_ in g_t0)),
+                  "note": "library option deterministic=1 (+ deferred_accum): runs ordered by ray, pieces of long runs added in wave order, no learnt first-slab widths / carried order / lagged box, one host wait per forward"}
+        del tr_t
+
     # ---------------- the step with a full Morton sort in EVERY build (library option carry_order=0; the headline's builds keep the order of the last
     # sort for up to 32 builds -- what a training loop's builds do between optimizer steps -- and sort again when it has decayed)
     full_sort = None
@@ -634,6 +660,8 @@ def main():
             res["value_varying"] = varying
         if deferred is not None:
             res["value_deferred_accum"] = deferred
+        if determ is not None:
+            res["value_deterministic"] = determ
         if full_sort is not None:
             res["value_sort_every_build"] = full_sort
         if args.check_sum:

@@ -178,7 +178,11 @@ long long lrt_debug_read(lrt_state* st, int which, void* host_dst, long long max
  * carry_order (1 [default]: a build of an unchanged P keeps the Morton order of the last full sort; carry_max_age 32 builds, carry_max_inv 20 per mille
  * of neighbours out of order make the next build sort again; 0: sort in every build like the reference's rebuild); ray_set (N >= 0 names the rays of
  * the next forwards -- a training loop's frame index: what the forward learns per tile (first-slab widths, tile lengths, queue boundaries) is kept per
- * name, 256 names; -1 [default]: unnamed); lpt, learn_slab, bk_columns, zero_in_prep (A/B switches of the schedule and of the backward's ray groups /
+ * name, 256 names; -1 [default]: unnamed); deterministic (1: bit-reproducible results that do not depend on earlier calls -- the backward adds a
+ * Gaussian's records up in the order of their rays and the pieces of a run that crosses waves in wave order instead of the arrival order of atomics;
+ * the forward runs without its learnt tables [learn_slab, carry_order, lag_bounds off] and a training forward waits for its status words and runs
+ * again with a larger hit record when the frame did not fit, so that no result comes from a fallback; the caller adds deferred_accum: the forward's
+ * hit weights are float atomics; about 1.45 x the default step; 0 [default]); lpt, learn_slab, bk_columns, zero_in_prep (A/B switches of the schedule and of the backward's ray groups /
  * zero fill: DESIGN.md 4.2 / 4.3).  bwd_mode 1 / 2, defer_colour 0 and fused_tree 0 / 2 exist in the cross-check library only (lrt_has_legacy).
  * The full list is lrt_set_option in lrt_kernels.hip. */
 int lrt_set_option(lrt_state* st, const char* name, int value);

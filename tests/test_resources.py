@@ -29,10 +29,10 @@ def test_no_shipped_kernel_spills_a_vector_register_or_uses_scratch(table):
         assert r["vgpr_spill"] == 0 and r["scratch_bytes"] == 0 and not r["dynamic_stack"], (n, r)
 
 
-def test_the_product_library_ships_at_most_35_kernels_and_no_retired_generation(table):
+def test_the_product_library_ships_at_most_36_kernels_and_no_retired_generation(table):
     own = _own(table)
     names = sorted({n.split("<")[0] for n in own})                          # kernel DEFINITIONS (a template counts once, like `grep __global__`)
-    assert len(names) <= 35, (len(names), names)
+    assert len(names) <= 36, (len(names), names)                             # 35 of the round-6 cut + k_bwd_fixup (option deterministic)
     retired = ("k_bwd_reduce3", "k_bwd_replay", "k_bwd_prep<", "k_fwd_cr4<false", "k_make_records", "k_level1", "k_upper", "k_tree_top",
                "k_cone_init", "k_cone_axis", "k_cone_angle", "k_grad_rows", "k_list_touched", "k_list_foreign", "k_owner", "kc_query<", "kc_query(")
     for n in own:
