@@ -36,7 +36,7 @@
 #include "lrt_math.h"
 
 // workgroups (one wave each) of the near-ray replay: normally the list is empty and all of them return at once
-#define LRT_NEAR_BLOCKS 1536
+#define LRT_NEAR_BLOCKS 2048
 #ifndef LRT_LEAF
 #define LRT_LEAF 8            // primitives per leaf (tested exhaustively by the packet)
 #endif
@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(256) k_fwd_init(int P, float* __restrict__ acc
     const int nb_ = (tree_nodes && gridDim.x > 1) ? (int)gridDim.x - 1 : (int)gridDim.x;       // the finishing workgroup takes no share of the fills
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = nb_ * blockDim.x;
     // [0..7] tile queues of the forward, [8] hit_ovf, [9] hit_count, [10] err_flag (8 = the culled build lost primitives), [11] ovf_count,
-    // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [16..23] tile queues of a re-tracing backward,
+    // [12] STICKY error bits (only the host clears them), [13] near rays of the forward, [15] k_fwd_near's ray tickets, [16..23] tile queues of a re-tracing backward,
     // [24] near rays found by the re-tracing backward, [25] its finished workgroups
     if (i < 32 && i != 12) ctrl[i] = (i == 10 && build_flag && *build_flag) ? 8u : 0u;      // ([32..95]: the build's order-decay counters, summed and cleared by the epilogue)
     if (i >= 32 && i < 40) ctrl[96 + 32 * (i - 32)] = 0u;         // k_fwd_cr4's eight ticket counters, a 128-byte line each: away from the words every tile adds to (hit_count)
@@ -1520,7 +1520,7 @@ static int forward_impl(lrt_state* st, int H, int W, const float* ray_o, const f
         HIPCHK(hipMalloc(&st->near_list, 2 * HW * sizeof(int)));      // [0, HW): the forward's list, [HW, 2 HW): the re-tracing backward's own
         st->near_cap = HW;
     }
-    tp.near_list = st->near_list; tp.near_count = st->ctrl + 13;
+    tp.near_list = st->near_list; tp.near_count = st->ctrl + 13; tp.near_done = st->ctrl + 15;      // (ctrl[15]: k_fwd_near's ray tickets; cleared with the block by k_fwd_init)
     const bool defer = st->fwd_mode == 2 && (size_t)P < ((size_t)1 << 26) && st->defer_colour;        // the colour pass reads the hit record
     const bool record = ((training && st->replay_enabled) || defer) && HW > 0 && P > 0;
     bool fin_done = false;
