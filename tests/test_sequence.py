@@ -84,3 +84,16 @@ def test_frame_order_is_a_function_of_seed_and_iteration_and_the_entry_point_ref
     assert "refusing" in capsys.readouterr().err
     with pytest.raises(SystemExit, match="needs a HIP device"):
         train.main(["--data", str(tmp_path), "--iters", "3"])
+
+
+def test_the_entry_point_refuses_deterministic_with_exact_accum_and_the_tracer_flag_implies_deferred_weights(tmp_path, capsys):
+    """--deterministic takes the hit weights from the backward (the forward's are float atomics in arrival order): together with --exact-accum it is refused
+    before any device is touched; `Tracer(deterministic=True)` implies `deferred_accum`."""
+    from lidar_rt_amd import train
+    with pytest.raises(SystemExit) as e:
+        train.main(["--data", str(tmp_path), "--iters", "3", "--deterministic", "--exact-accum"])
+    assert e.value.code == 2 and "--deterministic" in capsys.readouterr().err
+    from lidar_rt_amd.diff_lidar_tracer import Tracer
+    t = Tracer(deterministic=True)
+    assert t.deterministic and t.deferred_accum
+    assert not Tracer().deterministic and not Tracer().deferred_accum
